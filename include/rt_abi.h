@@ -1,0 +1,328 @@
+/*
+ * rt_abi.h -- C ABI of librt2_mi355x.so, the MI355X-native replacement for the
+ * per-pixel path-trace loop of addiswebb/ray_tracer_2.
+ *
+ * Everything in this header is plain C: fixed-layout POD structs, pointers and
+ * sizes.  No torch, HIP or C++ types cross the boundary.  A Rust (or any other
+ * FFI-capable) host binds exactly these symbols; INTEGRATION.md shows the
+ * replacement `src/rendering/ray_tracer.rs` a maintainer would add.
+ *
+ * Section 1 reproduces, byte for byte, the `#[repr(C)]`/bytemuck structs the
+ * reference uploads to its WGSL shader (citations are relative to the
+ * reference checkout).  Section 2 is the device-side API that replaces
+ * `RayTracer::{new, create_gpu_resources, load_scene_gpu_resources,
+ * update_buffers, render}` (src/rendering/ray_tracer.rs:49,316,237,397,420).
+ * Section 3 is the host-side scene pipeline (OBJ/MTL loader, SAH BVH builder,
+ * built-in scene library) that feeds it, replacing `AssetManager::load_model`
+ * (src/core/asset.rs:102), `BVH::build_per_mesh` (src/core/bvh.rs:152) and
+ * `Scene::instantiate_scene` (src/scene/scene.rs:179).
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* 1. Data contract (byte-exact with the reference)                          */
+/* ------------------------------------------------------------------------ */
+
+/* src/core/app.rs:27-40  <->  shaders/ray_tracer.wgsl:2-12 */
+typedef struct rt_params {
+    uint32_t width;
+    uint32_t height;
+    int32_t number_of_bounces; /* a path has number_of_bounces + 1 segments */
+    int32_t rays_per_pixel;
+    int32_t skybox;
+    int32_t frames; /* the seed: -1 after a reset, 0 first frame, ... */
+    int32_t accumulate;
+    int32_t debug_flag; /* 0 = path trace, 1..7 = debug views */
+    int32_t debug_scale;
+    float _p1[3];
+} rt_params;
+
+/* src/scene/components/material.rs:3-18  <->  wgsl:14-27 */
+typedef struct rt_material {
+    float color[4];
+    float emission_color[4];
+    float specular_color[4];
+    float absorption[4];
+    float absorption_strength;
+    float emission_strength;
+    float smoothness;
+    float specular;
+    float ior;
+    int32_t flag; /* RT_MATERIAL_* */
+    int32_t diffuse_index;
+    int32_t normal_index;
+} rt_material;
+
+enum { RT_MATERIAL_DEFAULT = 0, RT_MATERIAL_GLASS = 1, RT_MATERIAL_TEXTURE = 2 };
+
+/* src/scene/components/geometry/sphere.rs:4-10  <->  wgsl:29-33 */
+typedef struct rt_sphere {
+    float pos[3];
+    float radius;
+    rt_material material;
+} rt_sphere;
+
+/* src/scene/components/geometry/mesh.rs:52-62  <->  wgsl:35-42.
+ * Matrices are column-major ([col][row]), as glam's to_cols_array_2d. */
+typedef struct rt_mesh_uniform {
+    float world_to_model[4][4];
+    float model_to_world[4][4];
+    uint32_t node_offset;
+    uint32_t triangles;
+    uint32_t triangle_offset;
+    float _p1;
+    rt_material material;
+} rt_mesh_uniform;
+
+/* src/core/bvh.rs:55-66  <->  wgsl:60-67.  left/right are mesh-local node
+ * indices, first is a mesh-local triangle index, count > 0 marks a leaf. */
+typedef struct rt_node {
+    uint32_t left;
+    uint32_t right;
+    uint32_t first;
+    uint32_t count;
+    float aabb_min[3];
+    float _p1;
+    float aabb_max[3];
+    float _p2;
+} rt_node;
+
+/* src/core/bvh.rs:19-34  <->  wgsl:69-82 */
+typedef struct rt_packed_triangle {
+    float v1[3];
+    float uv10;
+    float v2[3];
+    float uv11;
+    float v3[3];
+    float uv20;
+    float n1[3];
+    float uv21;
+    float n2[3];
+    float uv30;
+    float n3[3];
+    float uv31;
+} rt_packed_triangle;
+
+/* src/scene/camera.rs:15-22  <->  wgsl:44-49 (84 bytes on the host) */
+typedef struct rt_camera_uniform {
+    float cam_to_world[4][4];
+    float view_params[3]; /* plane_width, plane_height, focus_dist */
+    float defocus_strength;
+    float diverge_strength;
+} rt_camera_uniform;
+
+/* src/scene/scene.rs:1016-1026  <->  wgsl:51-58.  The host layout is kept
+ * as is, including `nodes` at offset 100 (the shader never reads it). */
+typedef struct rt_scene_uniform {
+    uint32_t spheres;
+    uint32_t n_vertices;
+    uint32_t n_indices;
+    uint32_t meshes;
+    rt_camera_uniform camera;
+    uint32_t nodes;
+    float padding[6];
+} rt_scene_uniform;
+
+/* One RGBA8 sRGB texture as the reference uploads it
+ * (src/rendering/ray_tracer.rs:237-275): tightly packed rows, already
+ * flipped horizontally by the loader (src/core/asset.rs:77). */
+typedef struct rt_texture_desc {
+    const uint8_t* rgba8;
+    uint32_t width;
+    uint32_t height;
+} rt_texture_desc;
+
+/* Capacity limits the reference's fixed-size buffers impose
+ * (src/rendering/ray_tracer.rs:15-19, src/core/bvh.rs:140); kept as input
+ * validation. */
+#define RT_MAX_MESHES 400u
+#define RT_MAX_SPHERES 500u
+#define RT_MAX_TRIANGLES 1375000u
+#define RT_MAX_NODES 2600000u
+#define RT_MAX_TEXTURES 64u
+#define RT_BVH_STACK 32u /* wgsl:297 */
+
+/* status codes: 0 = ok, negative = error (text via rt_last_error) */
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_CAPACITY = -2,
+    RT_ERR_DEVICE = -3,
+    RT_ERR_NO_SCENE = -4,
+    RT_ERR_BVH_DEPTH = -5,
+    RT_ERR_IO = -6,
+    RT_ERR_PARSE = -7,
+    RT_ERR_OUT_OF_MEMORY = -8,
+    RT_ERR_INDEX_RANGE = -9
+};
+
+/* ------------------------------------------------------------------------ */
+/* 2. Device side: replaces RayTracer (src/rendering/ray_tracer.rs)          */
+/* ------------------------------------------------------------------------ */
+
+typedef struct rt_handle rt_handle;
+
+/* Counters of the last rt_render* call (device-side atomics, one add per
+ * wave).  `segments` counts calculate_ray_collions calls (wgsl:353) = rays. */
+typedef struct rt_stats {
+    uint64_t segments;
+    uint64_t paths;
+    uint64_t node_tests;     /* AABB tests, as wgsl:322 counts them */
+    uint64_t triangle_tests; /* as wgsl:307 counts them */
+    float kernel_ms;         /* hipEvent time of the render kernel(s) */
+    uint32_t _pad;
+} rt_stats;
+
+/* ≙ RayTracer::new + create_gpu_resources (ray_tracer.rs:49,316): picks the
+ * device, creates the stream and the RGBA32F accumulation image of up to
+ * max_width x max_height texels (engine.rs:142-158). */
+int rt_create(int device_ordinal, uint32_t max_width, uint32_t max_height, rt_handle** out);
+
+/* ≙ RayTracer::update_buffers (ray_tracer.rs:397-419), to be called when the
+ * scene changes instead of every frame.  All arrays are copied before return.
+ * Validates capacities, offsets and BVH depth (<= RT_BVH_STACK - 1). */
+int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere* spheres,
+                    uint32_t n_spheres, const rt_mesh_uniform* meshes, uint32_t n_meshes,
+                    const rt_packed_triangle* triangles, uint32_t n_triangles,
+                    const rt_node* nodes, uint32_t n_nodes);
+
+/* ≙ RayTracer::load_scene_gpu_resources (ray_tracer.rs:237-315). n <= 64. */
+int rt_upload_textures(rt_handle* h, const rt_texture_desc* descs, uint32_t n);
+
+/* The cheap per-frame part of update_buffers: only the camera changed. */
+int rt_set_camera(rt_handle* h, const rt_camera_uniform* camera);
+
+/* ≙ RayTracer::render (ray_tracer.rs:420-434): one frame of wgsl `main` over
+ * params->width x params->height; accumulates into the device image when
+ * params->frames >= 1 (wgsl:154-161).  Asynchronous on the handle's stream. */
+int rt_render(rt_handle* h, const rt_params* params);
+
+/* Multi-GPU tile split: renders only the 8-row strips s with
+ * s % world == rank into the compact local image (strip-major).  Seeds use
+ * the full-frame pixel index, so the stitched image equals rt_render's. */
+int rt_render_strips(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world);
+
+/* Number of texels rt_render_strips(rank, world) writes. */
+uint64_t rt_strip_texels(uint32_t width, uint32_t height, uint32_t rank, uint32_t world);
+
+/* Scatter a gathered [world][max_local_texels][4] float device buffer
+ * (rank-major, each rank padded to rt_strip_texels(.., 0, world)) into the
+ * handle's full-frame image. */
+int rt_assemble_strips(rt_handle* h, const void* gathered_device, uint32_t width, uint32_t height,
+                       uint32_t world);
+
+/* ≙ copy_texture_to_buffer in save_render_to_file (app.rs:341-407): blocking
+ * copy of width*height RGBA32F texels (row 0 = bottom of the view). */
+int rt_read_image(rt_handle* h, float* rgba32f_out, size_t bytes);
+/* Restore a previously read accumulation image (checkpoint/resume). */
+int rt_write_image(rt_handle* h, const float* rgba32f_in, size_t bytes);
+
+int rt_synchronize(rt_handle* h);
+int rt_get_stats(rt_handle* h, rt_stats* out);
+/* Enable/disable the optional per-ray counters (node/triangle tests). */
+int rt_set_counters(rt_handle* h, int enabled);
+/* Raw device pointer of the image / stream, for zero-copy interop
+ * (torch.distributed gathers over RCCL operate on this memory). */
+void* rt_device_image(rt_handle* h);
+void* rt_stream(rt_handle* h);
+
+const char* rt_last_error(rt_handle* h);
+void rt_destroy(rt_handle* h);
+
+/* Library-level queries (no device needed). */
+const char* rt_version(void);
+int rt_device_count(void);
+/* sizeof() of every struct above, for FFI self-checks:
+ * params, material, sphere, mesh, node, triangle, camera, scene. */
+void rt_abi_sizes(uint32_t out[8]);
+
+/* ------------------------------------------------------------------------ */
+/* 3. Host side: scene pipeline (no device needed)                           */
+/* ------------------------------------------------------------------------ */
+
+typedef struct rt_scene rt_scene;
+
+/* ≙ Scene::from_name + Scene::instantiate_scene (scene.rs:1003,179).
+ * name: "cornell_box", "room", "room_2", "metal", "balls", "sponza",
+ * "texture_test", "obj_test" (random_balls is unseeded in the reference and is
+ * not reproduced).  assets_dir ≙ CARGO_MANIFEST_DIR/assets (asset.rs:50,108). */
+int rt_scene_load_builtin(const char* name, const char* assets_dir, rt_scene** out);
+
+/* Scene-definition API ≙ SceneDefinition::{set_camera, add_mesh, add_sphere}
+ * (scene.rs:75-99). */
+typedef struct rt_transform {
+    float pos[3];
+    float rot[4]; /* quaternion x, y, z, w */
+    float scale[3];
+} rt_transform;
+
+typedef struct rt_camera_desc { /* ≙ CameraDescriptor (camera.rs:38-66) */
+    rt_transform transform;
+    float fov;
+    float aspect;
+    float near_plane;
+    float far_plane;
+    float focus_dist;
+    float defocus_strength;
+    float diverge_strength;
+} rt_camera_desc;
+
+int rt_scene_create(rt_scene** out);
+int rt_scene_set_camera(rt_scene* s, const rt_camera_desc* cam);
+/* ≙ Transform::cam (transform.rs:13-19): look-at camera transform. */
+void rt_transform_cam(const float origin[3], const float look_at[3], rt_transform* out);
+int rt_scene_add_sphere(rt_scene* s, const float centre[3], float radius, const rt_material* m);
+/* MeshDefinition::FromFile (mesh.rs:33-36) */
+int rt_scene_add_obj(rt_scene* s, const char* assets_dir, const char* path,
+                     const rt_transform* t, int use_mtl, const rt_material* m);
+/* MeshDefinition::FromData: n_vertices x (pos[3], normal[3], uv[2]) floats */
+int rt_scene_add_mesh_data(rt_scene* s, const float* vertices8, uint32_t n_vertices,
+                           const uint32_t* indices, uint32_t n_indices,
+                           const rt_transform* t, const rt_material* m);
+/* Texture registration for material.diffuse_index; returns the index or <0. */
+int rt_scene_add_texture_rgba8(rt_scene* s, const uint8_t* rgba8, uint32_t w, uint32_t h);
+/* ≙ BVH::build_per_mesh(meshes, Quality::High) (bvh.rs:152-207);
+ * quality: 0 = Low, 1 = High, 2 = Disabled (bvh.rs:126-131). */
+int rt_scene_build(rt_scene* s, int quality);
+
+/* Accessors: pointers stay valid until the scene is modified or destroyed. */
+int rt_scene_get_uniform(const rt_scene* s, rt_scene_uniform* out); /* ≙ Scene::to_uniform */
+uint32_t rt_scene_num_spheres(const rt_scene* s);
+uint32_t rt_scene_num_meshes(const rt_scene* s);
+uint32_t rt_scene_num_triangles(const rt_scene* s);
+uint32_t rt_scene_num_nodes(const rt_scene* s);
+uint32_t rt_scene_num_textures(const rt_scene* s);
+const rt_sphere* rt_scene_spheres(const rt_scene* s);
+const rt_mesh_uniform* rt_scene_meshes(const rt_scene* s);
+const rt_packed_triangle* rt_scene_triangles(const rt_scene* s);
+const rt_node* rt_scene_nodes(const rt_scene* s);
+int rt_scene_get_texture(const rt_scene* s, uint32_t i, rt_texture_desc* out);
+const char* rt_scene_mesh_label(const rt_scene* s, uint32_t i);
+const char* rt_scene_last_error(const rt_scene* s);
+void rt_scene_destroy(rt_scene* s);
+
+/* Convenience: upload everything a built scene holds to a device handle
+ * (≙ load_scene_gpu_resources + update_buffers). */
+int rt_upload_built_scene(rt_handle* h, const rt_scene* s);
+
+/* Uniform n x n barycentric split of every triangle of every mesh added so
+ * far (SURVEY 8d stand-in for the missing Dragon_80K / dragon_large assets). */
+int rt_scene_subdivide_meshes(rt_scene* s, uint32_t n);
+
+/* ≙ the pixel loop of save_render_to_file (app.rs:408-460): gamma 1/2.2,
+ * clamp, truncating u8, net vertical flip.  out: width*height*4 bytes. */
+int rt_export_rgba8(const float* rgba32f, uint32_t width, uint32_t height, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT_ABI_H */

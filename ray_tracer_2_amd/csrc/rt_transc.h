@@ -1,0 +1,333 @@
+// rt_transc.h -- the canonical f32 transcendental functions of this build.
+//
+// WGSL leaves the precision of log, cos, sin, exp, exp2, log2, pow, acos and
+// atan2 to the driver (naga 25 / Vulkan; SURVEY.md 8c "parity unpinned"), so
+// a path tracer cannot be compared across math libraries: a 1-ULP change in a
+// bounce direction occasionally flips a hit or a Russian-roulette decision.
+// This header therefore DEFINES those functions once, in IEEE binary32
+// arithmetic only (+, -, *, /, sqrt, fma, integer bit operations -- all of
+// them correctly rounded on both x86-64 and gfx950), and both the HIP kernel
+// (rt_kernel.hip) and the CPU oracle (oracle/shader_oracle.cpp) evaluate
+// exactly these bodies.  Results are bit-identical on host and device when
+// compiled with -ffp-contract=off (every fused operation below is an explicit
+// fma).  tests/test_transc.py bounds their error against double-precision
+// libm (<= 2 ULP on the ranges the shader uses).
+//
+// Algorithms: argument reduction + polynomial kernels in the style of the
+// classic float libm routines (log: msun e_logf; sin/cos: msun k_sinf/k_cosf
+// with a 3-term Cody-Waite reduction; exp2/exp: own minimax polynomials;
+// atan/asin: Cephes atanf/asinf).  msun notice: "Developed at SunPro, a Sun
+// Microsystems, Inc. business. Permission to use, copy, modify, and
+// distribute this software is freely granted, provided that this notice is
+// preserved."
+#ifndef RT_TRANSC_H
+#define RT_TRANSC_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rtm {
+
+RT_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+RT_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+RT_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RT_HD float sqrt_(float x) { return __builtin_sqrtf(x); }  // IEEE correctly rounded
+RT_HD float rint_(float x) { return __builtin_rintf(x); }  // round to nearest even
+RT_HD float abs_(float x) { return u2f(f2u(x) & 0x7fffffffu); }
+
+// 2^k * p for finite p, any int k (two-step so that the intermediate factors
+// stay normal; a subnormal result is rounded once more, deterministically).
+RT_HD float scale2(float p, int k) {
+    if (k > 127) {
+        p = p * 0x1p127f;
+        k -= 127;
+        if (k > 127) {
+            p = p * 0x1p127f;
+            k -= 127;
+            if (k > 127) k = 127;
+        }
+    } else if (k < -126) {
+        p = p * 0x1p-102f;  // 2^-126 * 2^24
+        k += 102;
+        if (k < -126) {
+            p = p * 0x1p-102f;
+            k += 102;
+            if (k < -126) k = -126;
+        }
+    }
+    return p * u2f((uint32_t)(k + 127) << 23);
+}
+
+// ---------------------------------------------------------------- log ----
+// Returns k and f with x = 2^k * (1 + f), sqrt(1/2) <= 1 + f < sqrt(2),
+// for positive finite x.
+struct LogRed {
+    float f;
+    int k;
+};
+
+RT_HD LogRed log_reduce(float x) {
+    int32_t ix = (int32_t)f2u(x);
+    int k = 0;
+    if (ix < 0x00800000) {  // subnormal: scale up
+        x = x * 0x1p25f;
+        ix = (int32_t)f2u(x);
+        k = -25;
+    }
+    k += (ix >> 23) - 127;
+    ix &= 0x007fffff;
+    int32_t i = (ix + (0x95f64 << 3)) & 0x800000;
+    float m = u2f((uint32_t)(ix | (i ^ 0x3f800000)));  // m or m/2
+    k += (i >> 23);
+    LogRed r;
+    r.f = m - 1.0f;
+    r.k = k;
+    return r;
+}
+
+// log(1+f) - f + f*f/2 == s*(hfsq + R), msun polynomial
+RT_HD float log1p_kernel(float f, float* hfsq_out) {
+    const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f, Lg3 = 0.28498786688f,
+                Lg4 = 0.24279078841f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float w = z * z;
+    float t1 = w * (Lg2 + w * Lg4);
+    float t2 = z * (Lg1 + w * Lg3);
+    float R = t2 + t1;
+    float hfsq = (0.5f * f) * f;
+    *hfsq_out = hfsq;
+    return s * (hfsq + R);
+}
+
+RT_HD float log_(float x) {
+    uint32_t ux = f2u(x);
+    if ((ux & 0x7fffffffu) == 0) return u2f(0xff800000u);  // log(+-0) = -inf
+    if (ux >= 0x7f800000u) {
+        if (ux == 0x7f800000u) return x;    // +inf
+        if (ux > 0xff800000u || (ux > 0x7f800000u && ux < 0x80000000u))
+            return x + x;                   // NaN
+        return u2f(0x7fc00000u);            // negative -> NaN
+    }
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    LogRed r = log_reduce(x);
+    float hfsq;
+    float sr = log1p_kernel(r.f, &hfsq);
+    float dk = (float)r.k;
+    return (((sr + dk * ln2_lo) - hfsq) + r.f) + dk * ln2_hi;
+}
+
+RT_HD float log2_(float x) {
+    uint32_t ux = f2u(x);
+    if ((ux & 0x7fffffffu) == 0) return u2f(0xff800000u);
+    if (ux >= 0x7f800000u) {
+        if (ux == 0x7f800000u) return x;
+        if (ux > 0xff800000u || (ux > 0x7f800000u && ux < 0x80000000u)) return x + x;
+        return u2f(0x7fc00000u);
+    }
+    // log2(x) = k + log(1+f)/ln2, with log(1+f) split into hi + lo so the
+    // product with 1/ln2 keeps ~30 bits.
+    const float ivln2hi = 1.4428710938e+00f, ivln2lo = -1.7605285393e-04f;
+    LogRed r = log_reduce(x);
+    float hfsq;
+    float sr = log1p_kernel(r.f, &hfsq);
+    float hi = r.f - hfsq;
+    hi = u2f(f2u(hi) & 0xfffff000u);
+    float lo = ((r.f - hi) - hfsq) + sr;
+    float dk = (float)r.k;
+    return (((lo + hi) * ivln2lo + lo * ivln2hi) + hi * ivln2hi) + dk;
+}
+
+// --------------------------------------------------------------- exp2 ----
+// 2^r for |r| <= 0.5: degree-7 polynomial in r (Taylor/minimax of exp(r ln2)).
+RT_HD float exp2_kernel(float r) {
+    const float c1 = 6.9314718056e-01f, c2 = 2.4022650696e-01f, c3 = 5.5504108665e-02f,
+                c4 = 9.6181291076e-03f, c5 = 1.3333558146e-03f, c6 = 1.5403530393e-04f,
+                c7 = 1.5252733804e-05f;
+    float p = fma_(c7, r, c6);
+    p = fma_(p, r, c5);
+    p = fma_(p, r, c4);
+    p = fma_(p, r, c3);
+    p = fma_(p, r, c2);
+    p = fma_(p, r, c1);
+    return fma_(p, r, 1.0f);
+}
+
+RT_HD float exp2_(float x) {
+    uint32_t ax = f2u(x) & 0x7fffffffu;
+    if (ax > 0x7f800000u) return x + x;                  // NaN
+    if (x >= 128.0f) return u2f(0x7f800000u);            // overflow (incl. +inf)
+    if (x < -150.0f) return 0.0f;                        // underflow (incl. -inf)
+    float kf = rint_(x);
+    float r = x - kf;  // exact
+    return scale2(exp2_kernel(r), (int)kf);
+}
+
+RT_HD float exp_(float x) {
+    uint32_t ax = f2u(x) & 0x7fffffffu;
+    if (ax > 0x7f800000u) return x + x;
+    if (x > 88.72284f) return u2f(0x7f800000u);
+    if (x < -104.0f) return 0.0f;
+    // x = k ln2 + t, |t| <= ln2/2; e^t = 2^(t/ln2) evaluated as exp2_kernel
+    const float invln2 = 1.4426950216e+00f, ln2HI = 6.9314575195e-01f, ln2LO = 1.4286067653e-06f;
+    float kf = rint_(x * invln2);
+    float t = fma_(-kf, ln2HI, x);
+    t = fma_(-kf, ln2LO, t);
+    // e^t via its own polynomial (degree 6)
+    const float d2 = 0.5f, d3 = 1.6666667163e-01f, d4 = 4.1666667908e-02f, d5 = 8.3333337680e-03f,
+                d6 = 1.3888889225e-03f, d7 = 1.9841270114e-04f;
+    float p = fma_(d7, t, d6);
+    p = fma_(p, t, d5);
+    p = fma_(p, t, d4);
+    p = fma_(p, t, d3);
+    p = fma_(p, t, d2);
+    p = fma_(p, t * t, t);
+    p = p + 1.0f;
+    return scale2(p, (int)kf);
+}
+
+// WGSL: pow(x, y) = exp2(y * log2(x))  
+RT_HD float pow_(float x, float y) { return exp2_(y * log2_(x)); }
+
+// ------------------------------------------------------------ sin/cos ----
+RT_HD float sin_kernel(float x) {
+    const float S1 = -1.6666667163e-01f, S2 = 8.3333337680e-03f, S3 = -1.9841270114e-04f,
+                S4 = 2.7557314297e-06f, S5 = -2.5050759689e-08f, S6 = 1.5896910177e-10f;
+    float z = x * x;
+    float v = z * x;
+    float r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return x + v * (S1 + z * r);
+}
+
+RT_HD float cos_kernel(float x) {
+    const float C1 = 4.1666667908e-02f, C2 = -1.3888889225e-03f, C3 = 2.4801587642e-05f,
+                C4 = -2.7557314297e-07f, C5 = 2.0875723372e-09f, C6 = -1.1359647598e-11f;
+    float z = x * x;
+    float r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    uint32_t ix = f2u(x) & 0x7fffffffu;
+    if (ix < 0x3e99999au) {  // |x| < 0.3
+        return 1.0f - (0.5f * z - z * r);
+    }
+    float qx = (ix > 0x3f480000u) ? 0.28125f : u2f(ix - 0x01000000u);  // ~|x|/4
+    float hz = 0.5f * z - qx;
+    float a = 1.0f - qx;
+    return a - (hz - z * r);
+}
+
+// x = n*(pi/2) + r, |r| <= ~pi/4.  Three-term Cody-Waite with fma; accurate
+// for |x| < ~1e5 (the shader only passes angles in [0, 2*pi]).
+struct TrigRed {
+    float r;
+    int q;
+};
+
+RT_HD TrigRed trig_reduce(float x) {
+    const float invpio2 = 6.3661974669e-01f;
+    const float P1 = 1.5707963705e+00f;   // fl(pi/2)
+    const float P2 = -4.3711388287e-08f;  // fl(pi/2 - P1)
+    const float P3 = -1.7151245100e-15f;  // fl(pi/2 - P1 - P2)
+    float n = rint_(x * invpio2);
+    float r = fma_(-n, P1, x);
+    r = fma_(-n, P2, r);
+    r = fma_(-n, P3, r);
+    TrigRed t;
+    t.r = r;
+    t.q = (int)n & 3;
+    return t;
+}
+
+RT_HD float sin_(float x) {
+    uint32_t ax = f2u(x) & 0x7fffffffu;
+    if (ax >= 0x7f800000u) return x - x;  // inf/NaN -> NaN
+    if (ax < 0x3f490fdau) return sin_kernel(x);  // |x| < pi/4
+    TrigRed t = trig_reduce(x);
+    float s = sin_kernel(t.r), c = cos_kernel(t.r);
+    float v = (t.q & 1) ? c : s;
+    return (t.q & 2) ? -v : v;
+}
+
+RT_HD float cos_(float x) {
+    uint32_t ax = f2u(x) & 0x7fffffffu;
+    if (ax >= 0x7f800000u) return x - x;
+    if (ax < 0x3f490fdau) return cos_kernel(x);
+    TrigRed t = trig_reduce(x);
+    float s = sin_kernel(t.r), c = cos_kernel(t.r);
+    float v = (t.q & 1) ? s : c;
+    return ((t.q + 1) & 2) ? -v : v;
+}
+
+// ---------------------------------------------------------- atan/acos ----
+RT_HD float atan_pos(float x) {  // x >= 0 finite or +inf
+    float y;
+    if (x > 2.414213562373095f) {
+        y = 1.5707963705e+00f;
+        x = -(1.0f / x);
+    } else if (x > 0.4142135623730950f) {
+        y = 7.8539818525e-01f;
+        x = (x - 1.0f) / (x + 1.0f);
+    } else {
+        y = 0.0f;
+    }
+    float z = x * x;
+    float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z -
+               3.33329491539e-1f) * z * x + x;
+    return y + p;
+}
+
+RT_HD float atan_(float x) {
+    uint32_t ux = f2u(x);
+    if ((ux & 0x7fffffffu) > 0x7f800000u) return x + x;
+    float r = atan_pos(abs_(x));
+    return (ux >> 31) ? -r : r;
+}
+
+RT_HD float atan2_(float y, float x) {
+    const float PI = 3.14159274101f, PIO2 = 1.57079637051f;
+    uint32_t ux = f2u(x), uy = f2u(y);
+    uint32_t ax = ux & 0x7fffffffu, ay = uy & 0x7fffffffu;
+    if (ax > 0x7f800000u || ay > 0x7f800000u) return x + y;  // NaN
+    bool xneg = (ux >> 31) != 0, yneg = (uy >> 31) != 0;
+    if (ay == 0) {  // y = +-0
+        float r = xneg ? PI : 0.0f;
+        return yneg ? -r : r;
+    }
+    if (ax == 0) return yneg ? -PIO2 : PIO2;
+    if (ax == 0x7f800000u) {
+        float r;
+        if (ay == 0x7f800000u) r = xneg ? 3.0f * 7.8539818525e-01f : 7.8539818525e-01f;
+        else r = xneg ? PI : 0.0f;
+        return yneg ? -r : r;
+    }
+    if (ay == 0x7f800000u) return yneg ? -PIO2 : PIO2;
+    float a = atan_pos(abs_(y) / abs_(x));  // in [0, pi/2]
+    float r = xneg ? (PI - a) : a;
+    return yneg ? -r : r;
+}
+
+RT_HD float asin_core(float a) {  // 0 <= a <= 0.5 : asin(a)
+    float z = a * a;
+    float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z +
+                7.4953002686e-2f) * z + 1.6666752422e-1f) * z * a + a;
+    return p;
+}
+
+RT_HD float acos_(float x) {
+    const float PI = 3.14159274101f, PIO2 = 1.57079637051f;
+    uint32_t ax = f2u(x) & 0x7fffffffu;
+    if (ax > 0x7f800000u) return x + x;
+    if (ax > 0x3f800000u) return u2f(0x7fc00000u);  // |x| > 1
+    if (x < -0.5f) return PI - 2.0f * asin_core(sqrt_(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * asin_core(sqrt_(0.5f * (1.0f - x)));
+    float a = abs_(x);
+    float s = asin_core(a);
+    return (f2u(x) >> 31) ? (PIO2 + s) : (PIO2 - s);
+}
+
+}  // namespace rtm
+
+#endif  // RT_TRANSC_H
