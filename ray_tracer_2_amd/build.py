@@ -1,0 +1,80 @@
+"""Build recipes: the HIP/C++ product library and (separately) the CPU oracle.
+
+`hipcc` cross-compiles gfx950 without a GPU.  The product library is built
+in-tree (ray_tracer_2_amd/librt2_mi355x.so) so it travels with the repo
+snapshot; the oracle goes to oracle/_build/.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ray_tracer_2_amd", "csrc")
+PRODUCT_SO = os.path.join(ROOT, "ray_tracer_2_amd", "librt2_mi355x.so")
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "librt_oracle.so")
+
+PRODUCT_SOURCES = [
+    "rt_kernel.hip", "rt_api.hip", "host/obj_loader.cpp", "host/bvh.cpp", "host/scene.cpp",
+    "host/png_decode.cpp", "host/scene_capi.cpp", "host/ray_tracer.cpp",
+]
+PRODUCT_HEADERS = [
+    "rt_transc.h", "rt_texture.h", "rt_srgb_lut.h", "rt_device.h", "host/glam_math.h",
+    "host/obj_loader.h", "host/bvh.h", "host/scene.h", "host/ray_tracer.hpp",
+    "../../include/rt_abi.h",
+]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+
+
+def hipcc_path():
+    for p in ("/opt/rocm/bin/hipcc", "hipcc"):
+        if os.path.exists(p) or p == "hipcc":
+            return p
+
+
+def build_product(force=False, extra_flags=()):
+    srcs = [os.path.join(CSRC, s) for s in PRODUCT_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in PRODUCT_HEADERS]
+    if not force and not _newer(PRODUCT_SO, deps):
+        return PRODUCT_SO
+    # -ffp-contract=off: the canonical arithmetic is unfused (every fused
+    # operation is an explicit fma in rt_transc.h); division and sqrt stay
+    # correctly rounded (hipcc default, no fast-math).
+    cmd = [hipcc_path(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
+           "-fno-fast-math", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
+           "-I", os.path.join(ROOT, "include"), *extra_flags, *srcs, "-lz", "-o", PRODUCT_SO]
+    _run(cmd)
+    return PRODUCT_SO
+
+
+def build_oracle(force=False):
+    src = os.path.join(ROOT, "oracle", "shader_oracle.cpp")
+    deps = [src] + [os.path.join(CSRC, h) for h in ("rt_transc.h", "rt_texture.h", "rt_srgb_lut.h")]
+    deps.append(os.path.join(ROOT, "include", "rt_abi.h"))
+    if not force and not _newer(ORACLE_SO, deps):
+        return ORACLE_SO
+    os.makedirs(os.path.dirname(ORACLE_SO), exist_ok=True)
+    flags = ["-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+             "-pthread", "-Wall", "-Wextra"]
+    try:
+        if " fma " in open("/proc/cpuinfo").read():
+            flags.append("-mfma")  # __builtin_fmaf -> vfmadd (same result as libm fmaf)
+    except OSError:
+        pass
+    _run(["g++", *flags, src, "-o", ORACLE_SO])
+    return ORACLE_SO
+
+
+if __name__ == "__main__":
+    build_product(force="--force" in sys.argv)
+    build_oracle(force="--force" in sys.argv)

@@ -15,6 +15,10 @@ struct rt_scene {
     std::string err;
 };
 
+namespace rt2 {
+const Scene& scene_of(const rt_scene* s) { return s->scene; }
+}  // namespace rt2
+
 namespace {
 
 Transform from_abi(const rt_transform* t) {

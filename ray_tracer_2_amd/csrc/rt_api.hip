@@ -1,0 +1,461 @@
+// rt_api.hip -- section 2 of include/rt_abi.h: the device-side C ABI that
+// replaces RayTracer (src/rendering/ray_tracer.rs) of the reference.
+//
+// Ownership and threading follow the reference's use of RayTracer: one handle
+// per device, calls from one thread at a time, inputs are borrowed and copied
+// before the call returns, errors are integer codes (never exceptions or
+// aborts across the boundary).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_device.h"
+#include "rt_srgb_lut.h"
+
+namespace rtd {
+hipError_t launch_render(const RenderArgs& a, hipStream_t stream);
+hipError_t launch_assemble(const float4* gathered, float4* image, uint32_t width, uint32_t height,
+                           uint32_t world, unsigned long long pad_texels, hipStream_t stream);
+}  // namespace rtd
+
+using namespace rtd;
+
+struct rt_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    uint32_t max_width = 0, max_height = 0;
+    float4* image = nullptr;
+    Counters* counters = nullptr;
+    float* srgb_lut = nullptr;
+    // scene
+    bool have_scene = false;
+    DMesh* meshes = nullptr;
+    rt_material* mesh_materials = nullptr;
+    float4* nodes = nullptr;
+    float4* tri_isect = nullptr;
+    float4* tri_shade = nullptr;
+    DSphere* spheres = nullptr;
+    rt_material* sphere_materials = nullptr;
+    DTexture* textures = nullptr;
+    std::vector<uint8_t*> texture_data;
+    uint32_t n_meshes = 0, n_spheres = 0, n_textures = 0, n_nodes = 0, n_triangles = 0;
+    uint32_t stack_entries = 1;
+    rt_camera_uniform camera{};
+    // last render
+    uint32_t last_width = 0, last_height = 0;
+    bool timed = false;
+    int count_tests = 0;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(rt_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(h, RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+void free_dev(T*& p) {
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+}
+
+void free_scene(rt_handle* h) {
+    free_dev(h->meshes);
+    free_dev(h->mesh_materials);
+    free_dev(h->nodes);
+    free_dev(h->tri_isect);
+    free_dev(h->tri_shade);
+    free_dev(h->spheres);
+    free_dev(h->sphere_materials);
+    h->have_scene = false;
+}
+
+void free_textures(rt_handle* h) {
+    for (uint8_t*& p : h->texture_data) free_dev(p);
+    h->texture_data.clear();
+    free_dev(h->textures);
+    h->n_textures = 0;
+}
+
+template <typename T>
+int upload(rt_handle* h, T*& dst, const T* src, size_t n) {
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    HIP_TRY(h, hipMalloc((void**)&dst, bytes));
+    if (n) HIP_TRY(h, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return RT_OK;
+}
+
+// Height (in edges) of the subtree under `root`, with index validation and a
+// visit budget that catches cycles.  Iterative: explicit (node, depth) stack.
+int mesh_bvh_height(const rt_node* nodes, uint32_t n_nodes, uint32_t node_offset,
+                    uint32_t tri_offset, uint32_t n_triangles, uint32_t& height, std::string& why) {
+    if (node_offset >= n_nodes) {
+        why = "mesh node_offset out of range";
+        return RT_ERR_INDEX_RANGE;
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> st;
+    st.emplace_back(node_offset, 0u);
+    uint64_t visits = 0;
+    height = 0;
+    while (!st.empty()) {
+        auto [idx, depth] = st.back();
+        st.pop_back();
+        if (++visits > (uint64_t)n_nodes + 1) {
+            why = "BVH has a cycle";
+            return RT_ERR_INDEX_RANGE;
+        }
+        const rt_node& nd = nodes[idx];
+        if (depth > height) height = depth;
+        if (nd.count > 0) {
+            if ((uint64_t)tri_offset + nd.first + nd.count > n_triangles) {
+                why = "leaf triangle range out of bounds";
+                return RT_ERR_INDEX_RANGE;
+            }
+        } else {
+            uint64_t a = (uint64_t)node_offset + nd.left, b = (uint64_t)node_offset + nd.right;
+            if (a >= n_nodes || b >= n_nodes) {
+                why = "BVH child index out of range";
+                return RT_ERR_INDEX_RANGE;
+            }
+            st.emplace_back((uint32_t)a, depth + 1);
+            st.emplace_back((uint32_t)b, depth + 1);
+        }
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_version(void) { return "ray_tracer_2_amd 0.1 (gfx950)"; }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void rt_abi_sizes(uint32_t out[8]) {
+    out[0] = sizeof(rt_params);
+    out[1] = sizeof(rt_material);
+    out[2] = sizeof(rt_sphere);
+    out[3] = sizeof(rt_mesh_uniform);
+    out[4] = sizeof(rt_node);
+    out[5] = sizeof(rt_packed_triangle);
+    out[6] = sizeof(rt_camera_uniform);
+    out[7] = sizeof(rt_scene_uniform);
+}
+
+const char* rt_last_error(rt_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int rt_create(int device_ordinal, uint32_t max_width, uint32_t max_height, rt_handle** out) {
+    if (!out || max_width == 0 || max_height == 0) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "bad arguments");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, RT_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    rt_handle* h = new (std::nothrow) rt_handle();
+    if (!h) return fail(nullptr, RT_ERR_OUT_OF_MEMORY, "out of host memory");
+    h->device = device_ordinal;
+    h->max_width = max_width;
+    h->max_height = max_height;
+    *out = h;
+    HIP_TRY(h, hipSetDevice(device_ordinal));
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipEventCreate(&h->ev_start));
+    HIP_TRY(h, hipEventCreate(&h->ev_stop));
+    size_t texels = (size_t)max_width * max_height;
+    HIP_TRY(h, hipMalloc((void**)&h->image, texels * sizeof(float4)));
+    HIP_TRY(h, hipMemsetAsync(h->image, 0, texels * sizeof(float4), h->stream));
+    HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(Counters)));
+    HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(Counters), h->stream));
+    static const float lut[256] = {RT_SRGB_LUT_VALUES};
+    HIP_TRY(h, hipMalloc((void**)&h->srgb_lut, sizeof(lut)));
+    HIP_TRY(h, hipMemcpyAsync(h->srgb_lut, lut, sizeof(lut), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return RT_OK;
+}
+
+void rt_destroy(rt_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_scene(h);
+    free_textures(h);
+    free_dev(h->image);
+    free_dev(h->counters);
+    free_dev(h->srgb_lut);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere* spheres,
+                    uint32_t n_spheres, const rt_mesh_uniform* meshes, uint32_t n_meshes,
+                    const rt_packed_triangle* triangles, uint32_t n_triangles, const rt_node* nodes,
+                    uint32_t n_nodes) {
+    if (!h || !scene) return fail(h, RT_ERR_INVALID_ARGUMENT, "null handle or scene");
+    if ((n_spheres && !spheres) || (n_meshes && !meshes) || (n_triangles && !triangles) || (n_nodes && !nodes))
+        return fail(h, RT_ERR_INVALID_ARGUMENT, "null array with non-zero count");
+    // ray_tracer.rs:15-19, bvh.rs:140
+    if (n_meshes > RT_MAX_MESHES) return fail(h, RT_ERR_CAPACITY, "more than 400 meshes");
+    if (n_spheres > RT_MAX_SPHERES) return fail(h, RT_ERR_CAPACITY, "more than 500 spheres");
+    if (n_triangles > RT_MAX_TRIANGLES) return fail(h, RT_ERR_CAPACITY, "more than 1375000 triangles");
+    if (n_nodes > RT_MAX_NODES) return fail(h, RT_ERR_CAPACITY, "more than 2600000 BVH nodes");
+    if (scene->spheres != n_spheres || scene->meshes != n_meshes)
+        return fail(h, RT_ERR_INVALID_ARGUMENT, "SceneUniform counts disagree with the array lengths");
+    HIP_TRY(h, hipSetDevice(h->device));
+
+    try {
+        // Derived per-mesh data + validation.
+        std::vector<DMesh> dm(n_meshes);
+        std::vector<rt_material> mm(n_meshes);
+        uint32_t max_height = 0;
+        for (uint32_t i = 0; i < n_meshes; ++i) {
+            const rt_mesh_uniform& m = meshes[i];
+            DMesh& d = dm[i];
+            memcpy(d.w2m, m.world_to_model, 64);
+            memcpy(d.m2w, m.model_to_world, 64);
+            d.node_offset = m.node_offset;
+            d.tri_offset = m.triangle_offset;
+            d.flags = 0;
+            if (i > 0 && memcmp(m.world_to_model, meshes[i - 1].world_to_model, 64) == 0) d.flags |= DMESH_SAME_XFORM;
+            if (m.material.flag == RT_MATERIAL_GLASS) d.flags |= DMESH_GLASS;
+            uint32_t height = 0;
+            std::string why;
+            int rc = mesh_bvh_height(nodes, n_nodes, m.node_offset, m.triangle_offset, n_triangles, height, why);
+            if (rc != RT_OK) return fail(h, rc, "mesh " + std::to_string(i) + ": " + why);
+            // The shader's stack holds 32 entries (wgsl:297); with the near
+            // child kept in a register this kernel needs `height` entries and
+            // the shader height + 1.  Deeper trees overflow the shader's
+            // stack (undefined clamped behaviour) and are rejected.
+            if (height + 1 > RT_BVH_STACK)
+                return fail(h, RT_ERR_BVH_DEPTH, "mesh " + std::to_string(i) + ": BVH deeper than the 32-entry traversal stack");
+            if (height > max_height) max_height = height;
+            d.root_count = nodes[m.node_offset].count;
+            mm[i] = m.material;
+        }
+        // Triangle re-layout (see rt_device.h).  The subtractions and the
+        // cross product are wgsl:261-263, evaluated once here in binary32.
+        std::vector<float4> ti((size_t)n_triangles * 3), ts((size_t)n_triangles * 4);
+        for (uint32_t t = 0; t < n_triangles; ++t) {
+            const rt_packed_triangle& p = triangles[t];
+            float abx = p.v2[0] - p.v1[0], aby = p.v2[1] - p.v1[1], abz = p.v2[2] - p.v1[2];
+            float acx = p.v3[0] - p.v1[0], acy = p.v3[1] - p.v1[1], acz = p.v3[2] - p.v1[2];
+            float nx = aby * acz - abz * acy;
+            float ny = abz * acx - abx * acz;
+            float nz = abx * acy - aby * acx;
+            ti[(size_t)t * 3 + 0] = make_float4(p.v1[0], p.v1[1], p.v1[2], nx);
+            ti[(size_t)t * 3 + 1] = make_float4(abx, aby, abz, ny);
+            ti[(size_t)t * 3 + 2] = make_float4(acx, acy, acz, nz);
+            ts[(size_t)t * 4 + 0] = make_float4(p.n1[0], p.n1[1], p.n1[2], p.uv10);
+            ts[(size_t)t * 4 + 1] = make_float4(p.n2[0], p.n2[1], p.n2[2], p.uv11);
+            ts[(size_t)t * 4 + 2] = make_float4(p.n3[0], p.n3[1], p.n3[2], p.uv20);
+            ts[(size_t)t * 4 + 3] = make_float4(p.uv21, p.uv30, p.uv31, 0.0f);
+        }
+        std::vector<DSphere> ds(n_spheres);
+        std::vector<rt_material> sm(n_spheres);
+        for (uint32_t i = 0; i < n_spheres; ++i) {
+            ds[i] = DSphere{spheres[i].pos[0], spheres[i].pos[1], spheres[i].pos[2], spheres[i].radius};
+            sm[i] = spheres[i].material;
+        }
+
+        free_scene(h);
+        int rc;
+        if ((rc = upload(h, h->meshes, dm.data(), dm.size())) != RT_OK) return rc;
+        if ((rc = upload(h, h->mesh_materials, mm.data(), mm.size())) != RT_OK) return rc;
+        static_assert(sizeof(rt_node) == 3 * sizeof(float4), "node layout");
+        if ((rc = upload(h, h->nodes, reinterpret_cast<const float4*>(nodes), (size_t)n_nodes * 3)) != RT_OK) return rc;
+        if ((rc = upload(h, h->tri_isect, ti.data(), ti.size())) != RT_OK) return rc;
+        if ((rc = upload(h, h->tri_shade, ts.data(), ts.size())) != RT_OK) return rc;
+        if ((rc = upload(h, h->spheres, ds.data(), ds.size())) != RT_OK) return rc;
+        if ((rc = upload(h, h->sphere_materials, sm.data(), sm.size())) != RT_OK) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
+        h->n_meshes = n_meshes;
+        h->n_spheres = n_spheres;
+        h->n_nodes = n_nodes;
+        h->n_triangles = n_triangles;
+        h->stack_entries = max_height ? max_height : 1;
+        h->camera = scene->camera;
+        h->have_scene = true;
+    } catch (const std::bad_alloc&) {
+        return fail(h, RT_ERR_OUT_OF_MEMORY, "out of host memory");
+    }
+    return RT_OK;
+}
+
+int rt_upload_textures(rt_handle* h, const rt_texture_desc* descs, uint32_t n) {
+    if (!h || (n && !descs)) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n > RT_MAX_TEXTURES) return fail(h, RT_ERR_CAPACITY, "Cannot load more than 64 textures");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_textures(h);
+    std::vector<DTexture> dt(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        size_t bytes = (size_t)descs[i].width * descs[i].height * 4;
+        uint8_t* p = nullptr;
+        if (bytes) {
+            if (!descs[i].rgba8) return fail(h, RT_ERR_INVALID_ARGUMENT, "texture without data");
+            HIP_TRY(h, hipMalloc((void**)&p, bytes));
+            h->texture_data.push_back(p);
+            HIP_TRY(h, hipMemcpyAsync(p, descs[i].rgba8, bytes, hipMemcpyHostToDevice, h->stream));
+        }
+        dt[i] = DTexture{p, descs[i].width, descs[i].height};
+    }
+    int rc = upload(h, h->textures, dt.data(), dt.size());
+    if (rc != RT_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->n_textures = n;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_handle* h, const rt_camera_uniform* camera) {
+    if (!h || !camera) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    h->camera = *camera;
+    return RT_OK;
+}
+
+int rt_set_counters(rt_handle* h, int enabled) {
+    if (!h) return RT_ERR_INVALID_ARGUMENT;
+    h->count_tests = enabled ? 1 : 0;
+    return RT_OK;
+}
+
+uint64_t rt_strip_texels(uint32_t width, uint32_t height, uint32_t rank, uint32_t world) {
+    if (world == 0 || rank >= world) return 0;
+    uint32_t strips = (height + 7) / 8;
+    uint32_t local = strips / world + (rank < strips % world ? 1 : 0);
+    return (uint64_t)local * 8u * width;
+}
+
+static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world) {
+    if (!h || !params) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!h->have_scene) return fail(h, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
+    if (world == 0 || rank >= world) return fail(h, RT_ERR_INVALID_ARGUMENT, "bad rank/world");
+    if (params->width == 0 || params->height == 0) return fail(h, RT_ERR_INVALID_ARGUMENT, "empty image");
+    if ((uint64_t)params->width * params->height > (uint64_t)h->max_width * h->max_height)
+        return fail(h, RT_ERR_CAPACITY, "image larger than the size given to rt_create");
+    HIP_TRY(h, hipSetDevice(h->device));
+    RenderArgs a{};
+    a.params = *params;
+    a.camera = h->camera;
+    a.meshes = h->meshes;
+    a.mesh_materials = h->mesh_materials;
+    a.nodes = h->nodes;
+    a.tri_isect = h->tri_isect;
+    a.tri_shade = h->tri_shade;
+    a.spheres = h->spheres;
+    a.sphere_materials = h->sphere_materials;
+    a.textures = h->textures;
+    a.srgb_lut = h->srgb_lut;
+    a.image = h->image;
+    a.counters = h->counters;
+    a.n_meshes = h->n_meshes;
+    a.n_spheres = h->n_spheres;
+    a.n_textures = h->n_textures;
+    a.stack_entries = h->stack_entries;
+    a.strip_rank = rank;
+    a.strip_world = world;
+    a.tiles_x = (params->width + 7) / 8;
+    uint32_t strips = (params->height + 7) / 8;
+    a.tiles_y = strips / world + (rank < strips % world ? 1 : 0);
+    a.count_tests = (uint32_t)h->count_tests;
+    HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(Counters), h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev_start, h->stream));
+    HIP_TRY(h, launch_render(a, h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev_stop, h->stream));
+    h->timed = true;
+    h->last_width = params->width;
+    h->last_height = params->height;
+    return RT_OK;
+}
+
+int rt_render(rt_handle* h, const rt_params* params) { return render_impl(h, params, 0, 1); }
+
+int rt_render_strips(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world) {
+    return render_impl(h, params, rank, world);
+}
+
+int rt_assemble_strips(rt_handle* h, const void* gathered_device, uint32_t width, uint32_t height, uint32_t world) {
+    if (!h || !gathered_device || world == 0) return fail(h, RT_ERR_INVALID_ARGUMENT, "bad arguments");
+    if ((uint64_t)width * height > (uint64_t)h->max_width * h->max_height)
+        return fail(h, RT_ERR_CAPACITY, "image larger than the size given to rt_create");
+    HIP_TRY(h, hipSetDevice(h->device));
+    unsigned long long pad = rt_strip_texels(width, height, 0, world);
+    HIP_TRY(h, launch_assemble((const float4*)gathered_device, h->image, width, height, world, pad, h->stream));
+    h->last_width = width;
+    h->last_height = height;
+    return RT_OK;
+}
+
+int rt_synchronize(rt_handle* h) {
+    if (!h) return RT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return RT_OK;
+}
+
+int rt_read_image(rt_handle* h, float* out, size_t bytes) {
+    if (!h || !out) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (bytes > (size_t)h->max_width * h->max_height * sizeof(float4))
+        return fail(h, RT_ERR_INVALID_ARGUMENT, "read larger than the image");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(out, h->image, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return RT_OK;
+}
+
+int rt_write_image(rt_handle* h, const float* in, size_t bytes) {
+    if (!h || !in) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (bytes > (size_t)h->max_width * h->max_height * sizeof(float4))
+        return fail(h, RT_ERR_INVALID_ARGUMENT, "write larger than the image");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->image, in, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return RT_OK;
+}
+
+int rt_get_stats(rt_handle* h, rt_stats* out) {
+    if (!h || !out) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    Counters c{};
+    HIP_TRY(h, hipMemcpy(&c, h->counters, sizeof(c), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->segments = c.segments;
+    out->paths = c.paths;
+    out->node_tests = c.node_tests;
+    out->triangle_tests = c.triangle_tests;
+    if (h->timed) {
+        float ms = 0.0f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_start, h->ev_stop));
+        out->kernel_ms = ms;
+    }
+    return RT_OK;
+}
+
+void* rt_device_image(rt_handle* h) { return h ? (void*)h->image : nullptr; }
+void* rt_stream(rt_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""Loader and prototypes of the C-ABI product library (include/rt_abi.h).
+
+The library is mandatory: there is no Python or CPU fallback for the render
+path.  Importing this module on a machine without the built .so raises.
+"""
+import ctypes as C
+import os
+
+from . import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt2_mi355x.so")
+
+# every symbol include/rt_abi.h declares
+EXPORTS = [
+    "rt_create", "rt_upload_scene", "rt_upload_textures", "rt_set_camera", "rt_render",
+    "rt_render_strips", "rt_strip_texels", "rt_assemble_strips", "rt_read_image", "rt_write_image",
+    "rt_synchronize", "rt_get_stats", "rt_set_counters", "rt_device_image", "rt_stream",
+    "rt_last_error", "rt_destroy", "rt_version", "rt_device_count", "rt_abi_sizes",
+    "rt_scene_load_builtin", "rt_scene_create", "rt_scene_set_camera", "rt_transform_cam",
+    "rt_scene_add_sphere", "rt_scene_add_obj", "rt_scene_add_mesh_data",
+    "rt_scene_add_texture_rgba8", "rt_scene_build", "rt_scene_get_uniform",
+    "rt_scene_num_spheres", "rt_scene_num_meshes", "rt_scene_num_triangles", "rt_scene_num_nodes",
+    "rt_scene_num_textures", "rt_scene_spheres", "rt_scene_meshes", "rt_scene_triangles",
+    "rt_scene_nodes", "rt_scene_get_texture", "rt_scene_mesh_label", "rt_scene_last_error",
+    "rt_scene_destroy", "rt_upload_built_scene", "rt_scene_subdivide_meshes", "rt_export_rgba8",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc, gfx950). There is no fallback path.")
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    sig = {
+        "rt_create": (i32, [i32, u32, u32, P(vp)]),
+        "rt_upload_scene": (i32, [vp, P(A.SceneUniform), vp, u32, vp, u32, vp, u32, vp, u32]),
+        "rt_upload_textures": (i32, [vp, P(A.TextureDesc), u32]),
+        "rt_set_camera": (i32, [vp, P(A.CameraUniform)]),
+        "rt_render": (i32, [vp, P(A.Params)]),
+        "rt_render_strips": (i32, [vp, P(A.Params), u32, u32]),
+        "rt_strip_texels": (u64, [u32, u32, u32, u32]),
+        "rt_assemble_strips": (i32, [vp, vp, u32, u32, u32]),
+        "rt_read_image": (i32, [vp, vp, C.c_size_t]),
+        "rt_write_image": (i32, [vp, vp, C.c_size_t]),
+        "rt_synchronize": (i32, [vp]),
+        "rt_get_stats": (i32, [vp, P(A.Stats)]),
+        "rt_set_counters": (i32, [vp, i32]),
+        "rt_device_image": (vp, [vp]),
+        "rt_stream": (vp, [vp]),
+        "rt_last_error": (C.c_char_p, [vp]),
+        "rt_destroy": (None, [vp]),
+        "rt_version": (C.c_char_p, []),
+        "rt_device_count": (i32, []),
+        "rt_abi_sizes": (None, [P(u32 * 8)]),
+        "rt_scene_load_builtin": (i32, [C.c_char_p, C.c_char_p, P(vp)]),
+        "rt_scene_create": (i32, [P(vp)]),
+        "rt_scene_set_camera": (i32, [vp, P(A.CameraDesc)]),
+        "rt_transform_cam": (None, [P(C.c_float * 3), P(C.c_float * 3), P(A.Transform)]),
+        "rt_scene_add_sphere": (i32, [vp, P(C.c_float * 3), C.c_float, P(A.Material)]),
+        "rt_scene_add_obj": (i32, [vp, C.c_char_p, C.c_char_p, P(A.Transform), i32, P(A.Material)]),
+        "rt_scene_add_mesh_data": (i32, [vp, vp, u32, vp, u32, P(A.Transform), P(A.Material)]),
+        "rt_scene_add_texture_rgba8": (i32, [vp, vp, u32, u32]),
+        "rt_scene_build": (i32, [vp, i32]),
+        "rt_scene_get_uniform": (i32, [vp, P(A.SceneUniform)]),
+        "rt_scene_num_spheres": (u32, [vp]),
+        "rt_scene_num_meshes": (u32, [vp]),
+        "rt_scene_num_triangles": (u32, [vp]),
+        "rt_scene_num_nodes": (u32, [vp]),
+        "rt_scene_num_textures": (u32, [vp]),
+        "rt_scene_spheres": (vp, [vp]),
+        "rt_scene_meshes": (vp, [vp]),
+        "rt_scene_triangles": (vp, [vp]),
+        "rt_scene_nodes": (vp, [vp]),
+        "rt_scene_get_texture": (i32, [vp, u32, P(A.TextureDesc)]),
+        "rt_scene_mesh_label": (C.c_char_p, [vp, u32]),
+        "rt_scene_last_error": (C.c_char_p, [vp]),
+        "rt_scene_destroy": (None, [vp]),
+        "rt_upload_built_scene": (i32, [vp, vp]),
+        "rt_scene_subdivide_meshes": (i32, [vp, u32]),
+        "rt_export_rgba8": (i32, [vp, u32, u32, vp]),
+    }
+    assert set(sig) == set(EXPORTS)
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # raises AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    sizes = (u32 * 8)()
+    L.rt_abi_sizes(C.byref(sizes))
+    expect = [C.sizeof(t) for t in (A.Params, A.Material, A.Sphere, A.MeshUniform, A.Node,
+                                    A.PackedTriangle, A.CameraUniform, A.SceneUniform)]
+    if list(sizes) != expect:
+        raise ImportError(f"ABI mismatch: library {list(sizes)} vs bindings {expect}")
+    _lib = L
+    return L
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rt error {code}: {msg}")
+        self.code = code

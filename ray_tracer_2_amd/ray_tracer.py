@@ -1,0 +1,113 @@
+"""`RayTracer`: Python face of the device-side C ABI, with the reference's
+method names (src/rendering/ray_tracer.rs:48-435).
+
+    rt = RayTracer(device=0, max_width=1920, max_height=1080)   # new + create_gpu_resources
+    rt.load_scene_gpu_resources(arrays)                        # textures
+    rt.update_buffers(arrays)                                  # scene arrays (on change)
+    rt.render(params)                                          # one frame (async)
+    img = rt.read_image(w, h)                                  # RGBA32F, row 0 = bottom
+
+The render path is the HIP library only; nothing here computes pixels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+from .lib import RtError, load
+from .scene import Scene, SceneArrays
+
+
+class RayTracer:
+    def __init__(self, device=0, max_width=1920, max_height=1080):
+        self._L = load()
+        self._h = C.c_void_p()
+        rc = self._L.rt_create(device, max_width, max_height, C.byref(self._h))
+        if rc < 0:
+            msg = self._L.rt_last_error(self._h).decode()
+            if self._h:
+                self._L.rt_destroy(self._h)
+                self._h = None
+            raise RtError(rc, msg)
+        self.max_width, self.max_height = max_width, max_height
+
+    def _check(self, rc):
+        if rc < 0:
+            raise RtError(rc, self._L.rt_last_error(self._h).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rt_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- reference-named methods --------------------------------------
+    def load_scene_gpu_resources(self, arrays):
+        descs, n = arrays.texture_descs()
+        self._check(self._L.rt_upload_textures(self._h, descs, n))
+
+    def update_buffers(self, arrays):
+        a = arrays
+        u = a.uniform
+        self._check(self._L.rt_upload_scene(
+            self._h, C.byref(u), a.spheres.ctypes.data, a.spheres.shape[0], a.meshes.ctypes.data,
+            a.meshes.shape[0], a.triangles.ctypes.data, a.triangles.shape[0], a.nodes.ctypes.data,
+            a.nodes.shape[0]))
+
+    def load_scene(self, scene):
+        """Scene (C++ object) or SceneArrays -> device."""
+        arrays = SceneArrays.from_scene(scene) if isinstance(scene, Scene) else scene
+        self.load_scene_gpu_resources(arrays)
+        self.update_buffers(arrays)
+        return arrays
+
+    def set_camera(self, camera_uniform):
+        self._check(self._L.rt_set_camera(self._h, C.byref(camera_uniform)))
+
+    def render(self, params):
+        self._check(self._L.rt_render(self._h, C.byref(params)))
+
+    def render_strips(self, params, rank, world):
+        self._check(self._L.rt_render_strips(self._h, C.byref(params), rank, world))
+
+    # ---- data movement / bookkeeping ----------------------------------
+    def synchronize(self):
+        self._check(self._L.rt_synchronize(self._h))
+
+    def read_image(self, width, height):
+        out = np.empty((height, width, 4), dtype=np.float32)
+        self._check(self._L.rt_read_image(self._h, out.ctypes.data, out.nbytes))
+        return out
+
+    def read_texels(self, n_texels):
+        out = np.empty((n_texels, 4), dtype=np.float32)
+        self._check(self._L.rt_read_image(self._h, out.ctypes.data, out.nbytes))
+        return out
+
+    def write_image(self, img):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        self._check(self._L.rt_write_image(self._h, img.ctypes.data, img.nbytes))
+
+    def assemble_strips(self, gathered_device_ptr, width, height, world):
+        self._check(self._L.rt_assemble_strips(self._h, gathered_device_ptr, width, height, world))
+
+    def set_counters(self, enabled):
+        self._check(self._L.rt_set_counters(self._h, int(enabled)))
+
+    def stats(self):
+        s = A.Stats()
+        self._check(self._L.rt_get_stats(self._h, C.byref(s)))
+        return s
+
+    @property
+    def device_image_ptr(self):
+        return self._L.rt_device_image(self._h)
+
+    @property
+    def stream_ptr(self):
+        return self._L.rt_stream(self._h)
+
+    def strip_texels(self, width, height, rank, world):
+        return int(self._L.rt_strip_texels(width, height, rank, world))
