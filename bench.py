@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mrays/s (and ms/frame) of the path-trace hot
+path on CornellBox-Original at 1920x1080, 8 spp, 4 bounces (BASELINE.json
+configs[1]), on N GPUs of one node.
+
+A "step" is one frame: one pass of the hot path (wgsl `main`) over the whole
+image with `Params.frames` advancing 0, 1, 2, ... (progressive accumulation on,
+as the reference's App::update does).  1 ray = 1 path segment = one
+calculate_ray_collions call (wgsl:353), counted exactly on the device.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The frame
+is split into 8-row strips dealt round-robin to the ranks (strong scaling: the
+frame is fixed); every step each rank renders its strips and ONE gather over
+xGMI assembles the frame on rank 0.  value = rays of the whole frame, all
+ranks, per second of the slowest rank.
+
+Prints one JSON line on rank 0 (contract in the task statement), with
+`roofline` (compulsory HBM bytes per launch / measured kernel time against the
+8 TB/s peak -- this path is VALU/latency-bound, so the fraction is small by
+construction; `roofline_valu` gives the instruction-issue view) and
+`cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SPP, BOUNCES = 1920, 1080, 8, 4
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def cpu_baseline(rt, arrays):
+    """Oracle (CPU restatement of ray_tracer.wgsl, NOT wgpu/lavapipe) on a
+    bounded sample of the same workload: evenly spaced 8-row strips of frame 0."""
+    from oracle import oracle
+    import numpy as np
+    cores = oracle.hardware_threads()
+    p = rt.make_params(WIDTH, HEIGHT, BOUNCES, SPP, skybox=1, frames=0)
+    img = np.zeros((HEIGHT, WIDTH, 4), np.float32)
+    n_strips = (HEIGHT + 7) // 8
+
+    def run(strips):
+        rows = np.concatenate([np.arange(s * 8, min(s * 8 + 8, HEIGHT)) for s in strips]).astype(np.uint32)
+        t0 = time.perf_counter()
+        _, st = oracle.render(p, arrays, image=img, rows=rows, threads=cores)
+        return st.segments, time.perf_counter() - t0
+
+    # calibrate on a few strips, then size the sample for ~12 s of wall time
+    cal = sorted(set(int(i * n_strips / 8) for i in range(8)))
+    seg, t = run(cal)
+    want = int(max(8, min(n_strips, 12.0 / max(t / len(cal), 1e-6))))
+    strips = sorted(set(int(i * n_strips / want) for i in range(want)))
+    seg, t = run(strips)
+    return {"value": seg / t / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{len(strips)} of {n_strips} evenly spaced 8-row strips of frame 0 of the same workload "
+                      f"({seg} rays in {t:.1f} s); CPU restatement of ray_tracer.wgsl, not wgpu/lavapipe"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+
+    import torch
+    import ray_tracer_2_amd as rt
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H = args.width, args.height
+    arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
+    tracer = rt.RayTracer(device=local_rank, max_width=W, max_height=H)
+    tracer.load_scene(arrays)
+
+    local_texels = tracer.strip_texels(W, H, rank, world)
+    pad_texels = tracer.strip_texels(W, H, 0, world)
+    if world > 1:
+        # render straight into a torch tensor that RCCL will send
+        local = torch.zeros((pad_texels, 4), dtype=torch.float32, device="cuda")
+        tracer.bind_image(local.data_ptr(), pad_texels)
+        gathered = torch.empty((world, pad_texels, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+        frame = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+        assembler = None
+        if rank == 0:
+            assembler = rt.RayTracer(device=local_rank, max_width=8, max_height=8)
+            assembler.bind_image(frame.data_ptr(), H * W)
+
+    def step(f):
+        p = rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=f)
+        if world == 1:
+            tracer.render(p)
+        else:
+            tracer.render_strips(p, rank, world)
+            tracer.synchronize()  # render stream -> before the collective reads `local`
+            dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                torch.cuda.current_stream().synchronize()
+                assembler.assemble_strips(gathered.data_ptr(), W, H, world)
+
+    def fence():
+        tracer.synchronize()
+        if world > 1:
+            if rank == 0:
+                assembler.synchronize()
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for f in range(args.warmup):
+        step(f)
+    fence()
+    tracer.reset_timing()
+    t0 = time.perf_counter()
+    for f in range(args.warmup, args.warmup + args.steps):
+        step(f)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    st = tracer.stats()
+    rays_local = float(st.segments)
+    kernel_ms = st.kernel_ms / max(st.launches, 1)
+    if world > 1:
+        t = torch.tensor([elapsed, rays_local, kernel_ms], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, rays, kernel_ms = float(tmax[0]), float(t[1]), float(tmax[2])
+    else:
+        rays = rays_local
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        mrays = rays / elapsed / 1e6
+        # compulsory bytes per launch: the frame's texels are read
+        # (frames >= 1) and written once, plus the scene once.
+        scene_bytes = arrays.meshes.nbytes + arrays.nodes.nbytes + arrays.triangles.nbytes + arrays.spheres.nbytes
+        texels = local_texels if world > 1 else W * H
+        algo_bytes = texels * 16 * 2 + scene_bytes
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s", "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"CornellBox-Original {W}x{H}, {SPP} spp, {BOUNCES} bounces "
+                                   "(BASELINE configs[1]); 8 meshes / 32 triangles / 32 BVH nodes",
+                       "frames": f"{args.warmup}..{args.warmup + args.steps - 1} (progressive accumulation)",
+                       "parallelism": "1 GPU" if world == 1 else f"8-row strips round-robin over {world} GPUs + 1 RCCL gather/frame",
+                       "rays_per_frame": rays / args.steps, "Mpaths/s": W * H * SPP * args.steps / elapsed / 1e6},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rt_render_kernel<false>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "path is FP32-VALU/latency-bound (SURVEY 8d, DESIGN.md): compulsory HBM bytes are ~66 MB/frame"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rt, arrays)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -170,15 +170,16 @@ enum {
 
 typedef struct rt_handle rt_handle;
 
-/* Counters of the last rt_render* call (device-side atomics, one add per
- * wave).  `segments` counts calculate_ray_collions calls (wgsl:353) = rays. */
+/* Counters accumulated over the rt_render* calls since the last
+ * rt_reset_timing (device-side atomics, one add per wave).  `segments` counts
+ * calculate_ray_collions calls (wgsl:353) = rays. */
 typedef struct rt_stats {
     uint64_t segments;
     uint64_t paths;
     uint64_t node_tests;     /* AABB tests, as wgsl:322 counts them */
     uint64_t triangle_tests; /* as wgsl:307 counts them */
-    float kernel_ms;         /* hipEvent time of the render kernel(s) */
-    uint32_t _pad;
+    float kernel_ms;         /* sum of the hipEvent times of `launches` render launches */
+    uint32_t launches;       /* render launches since the last rt_reset_timing */
 } rt_stats;
 
 /* ≙ RayTracer::new + create_gpu_resources (ray_tracer.rs:49,316): picks the
@@ -227,6 +228,11 @@ int rt_write_image(rt_handle* h, const float* rgba32f_in, size_t bytes);
 
 int rt_synchronize(rt_handle* h);
 int rt_get_stats(rt_handle* h, rt_stats* out);
+/* Zero the counters and forget the recorded launch times. */
+int rt_reset_timing(rt_handle* h);
+/* Render into caller-owned device memory of `texels` RGBA32F texels (e.g. a
+ * buffer a collective library will send); NULL restores the internal image. */
+int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
 /* Enable/disable the optional per-ray counters (node/triangle tests). */
 int rt_set_counters(rt_handle* h, int enabled);
 /* Raw device pointer of the image / stream, for zero-copy interop

@@ -31,6 +31,7 @@ def load():
             build_oracle()
         L = C.CDLL(ORACLE_SO)
         L.oracle_render.restype = C.c_int
+        L.oracle_render_rows.restype = C.c_int
         L.oracle_trace_pixel.restype = C.c_int
         L.oracle_next_random_number.restype = C.c_uint32
         L.oracle_next_random_number.argtypes = [C.POINTER(C.c_uint32)]
@@ -42,7 +43,19 @@ def load():
 
 
 def hardware_threads():
-    return load().oracle_hardware_threads()
+    """Threads worth starting: the affinity mask capped by the cgroup CPU quota."""
+    n = load().oracle_hardware_threads()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def _scene_args(arrays):
@@ -60,11 +73,17 @@ def render(params, arrays, image=None, rows=None, threads=None):
     if image is None:
         image = np.zeros((h, w, 4), dtype=np.float32)
     assert image.dtype == np.float32 and image.shape == (h, w, 4) and image.flags.c_contiguous
-    r0, r1 = rows if rows is not None else (0, h)
     st = OracleStats()
     threads = threads or hardware_threads()
-    rc = L.oracle_render(C.byref(params), *_scene_args(arrays), C.c_void_p(image.ctypes.data),
-                         C.c_uint32(r0), C.c_uint32(r1), C.c_int(threads), C.byref(st))
+    if rows is None:
+        rows = (0, h)
+    if isinstance(rows, tuple):
+        row_list = np.arange(rows[0], min(rows[1], h), dtype=np.uint32)
+    else:
+        row_list = np.ascontiguousarray(rows, dtype=np.uint32)
+    rc = L.oracle_render_rows(C.byref(params), *_scene_args(arrays), C.c_void_p(image.ctypes.data),
+                              C.c_void_p(row_list.ctypes.data), C.c_uint32(row_list.size),
+                              C.c_int(threads), C.byref(st))
     assert rc == 0
     return image, st
 

@@ -572,37 +572,34 @@ typedef struct oracle_transcript {
     uint32_t rng_after;
 } oracle_transcript;
 
-// Renders rows [row_begin, row_end) of the frame into `image` (full-frame
-// RGBA32F, read-modify-write when params->frames >= 1) on n_threads threads,
-// one 8-row strip per task.
-int oracle_render(const rt_params* params, const rt_scene_uniform* scene, const rt_sphere* spheres,
-                  const rt_mesh_uniform* meshes, const rt_packed_triangle* triangles,
-                  const rt_node* nodes, const rt_texture_desc* textures, uint32_t n_textures,
-                  float* image, uint32_t row_begin, uint32_t row_end, int n_threads,
-                  oracle_stats* stats_out) {
-    if (!params || !scene || !image) return -1;
+// Renders the listed rows of the frame into `image` (full-frame RGBA32F,
+// read-modify-write when params->frames >= 1) on n_threads threads, one row
+// per task.
+int oracle_render_rows(const rt_params* params, const rt_scene_uniform* scene, const rt_sphere* spheres,
+                       const rt_mesh_uniform* meshes, const rt_packed_triangle* triangles,
+                       const rt_node* nodes, const rt_texture_desc* textures, uint32_t n_textures,
+                       float* image, const uint32_t* rows, uint32_t n_rows, int n_threads,
+                       oracle_stats* stats_out) {
+    if (!params || !scene || !image || (n_rows && !rows)) return -1;
     std::vector<rtm::TexView> tv(n_textures);
     for (uint32_t i = 0; i < n_textures; ++i) tv[i] = rtm::TexView{textures[i].rgba8, textures[i].width, textures[i].height};
     orc::Ctx c{*params, *scene, spheres, meshes, triangles, nodes, tv.data(), n_textures};
-    if (row_end > params->height) row_end = params->height;
     if (n_threads < 1) n_threads = 1;
-    uint32_t first_strip = row_begin / 8, last_strip = (row_end + 7) / 8;
-    std::atomic<uint32_t> next(first_strip);
+    std::atomic<uint32_t> next(0);
     std::atomic<uint64_t> seg(0), nt(0), tt(0);
     auto worker = [&]() {
         uint64_t segments = 0, n_tests = 0, t_tests = 0;
         for (;;) {
-            uint32_t s = next.fetch_add(1);
-            if (s >= last_strip) break;
-            uint32_t y0 = s * 8 < row_begin ? row_begin : s * 8;
-            uint32_t y1 = (s + 1) * 8 > row_end ? row_end : (s + 1) * 8;
-            for (uint32_t y = y0; y < y1; ++y)
-                for (uint32_t x = 0; x < params->width; ++x) {
-                    int32_t st[2] = {0, 0};
-                    orc::main_invocation(c, x, y, image, &segments, st, nullptr);
-                    n_tests += (uint64_t)st[0];
-                    t_tests += (uint64_t)st[1];
-                }
+            uint32_t k = next.fetch_add(1);
+            if (k >= n_rows) break;
+            uint32_t y = rows[k];
+            if (y >= params->height) continue;
+            for (uint32_t x = 0; x < params->width; ++x) {
+                int32_t st[2] = {0, 0};
+                orc::main_invocation(c, x, y, image, &segments, st, nullptr);
+                n_tests += (uint64_t)st[0];
+                t_tests += (uint64_t)st[1];
+            }
         }
         seg += segments; nt += n_tests; tt += t_tests;
     };
@@ -614,6 +611,20 @@ int oracle_render(const rt_params* params, const rt_scene_uniform* scene, const 
         stats_out->segments = seg; stats_out->node_tests = nt; stats_out->triangle_tests = tt;
     }
     return 0;
+}
+
+// Rows [row_begin, row_end).
+int oracle_render(const rt_params* params, const rt_scene_uniform* scene, const rt_sphere* spheres,
+                  const rt_mesh_uniform* meshes, const rt_packed_triangle* triangles,
+                  const rt_node* nodes, const rt_texture_desc* textures, uint32_t n_textures,
+                  float* image, uint32_t row_begin, uint32_t row_end, int n_threads,
+                  oracle_stats* stats_out) {
+    if (!params) return -1;
+    if (row_end > params->height) row_end = params->height;
+    std::vector<uint32_t> rows;
+    for (uint32_t y = row_begin; y < row_end; ++y) rows.push_back(y);
+    return oracle_render_rows(params, scene, spheres, meshes, triangles, nodes, textures, n_textures, image,
+                              rows.data(), (uint32_t)rows.size(), n_threads, stats_out);
 }
 
 // One pixel with a per-segment transcript; returns the number of records.

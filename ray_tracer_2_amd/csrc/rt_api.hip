@@ -26,7 +26,12 @@ using namespace rtd;
 struct rt_handle {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // one (start, stop) event pair per launch since the last rt_reset_timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    float4* own_image = nullptr;  // allocated by rt_create; `image` may be rebound
+    size_t image_texels = 0;
+    int32_t last_spp = 0;
     uint32_t max_width = 0, max_height = 0;
     float4* image = nullptr;
     Counters* counters = nullptr;
@@ -182,10 +187,10 @@ int rt_create(int device_ordinal, uint32_t max_width, uint32_t max_height, rt_ha
     *out = h;
     HIP_TRY(h, hipSetDevice(device_ordinal));
     HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIP_TRY(h, hipEventCreate(&h->ev_start));
-    HIP_TRY(h, hipEventCreate(&h->ev_stop));
     size_t texels = (size_t)max_width * max_height;
-    HIP_TRY(h, hipMalloc((void**)&h->image, texels * sizeof(float4)));
+    HIP_TRY(h, hipMalloc((void**)&h->own_image, texels * sizeof(float4)));
+    h->image = h->own_image;
+    h->image_texels = texels;
     HIP_TRY(h, hipMemsetAsync(h->image, 0, texels * sizeof(float4), h->stream));
     HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(Counters)));
     HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(Counters), h->stream));
@@ -202,11 +207,13 @@ void rt_destroy(rt_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_scene(h);
     free_textures(h);
-    free_dev(h->image);
+    free_dev(h->own_image);
     free_dev(h->counters);
     free_dev(h->srgb_lut);
-    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
-    if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    for (auto& e : h->ev_pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -354,8 +361,8 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     if (!h->have_scene) return fail(h, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
     if (world == 0 || rank >= world) return fail(h, RT_ERR_INVALID_ARGUMENT, "bad rank/world");
     if (params->width == 0 || params->height == 0) return fail(h, RT_ERR_INVALID_ARGUMENT, "empty image");
-    if ((uint64_t)params->width * params->height > (uint64_t)h->max_width * h->max_height)
-        return fail(h, RT_ERR_CAPACITY, "image larger than the size given to rt_create");
+    if (rt_strip_texels(params->width, params->height, rank, world) > h->image_texels)
+        return fail(h, RT_ERR_CAPACITY, "image larger than the bound image buffer");
     HIP_TRY(h, hipSetDevice(h->device));
     RenderArgs a{};
     a.params = *params;
@@ -381,11 +388,22 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     uint32_t strips = (params->height + 7) / 8;
     a.tiles_y = strips / world + (rank < strips % world ? 1 : 0);
     a.count_tests = (uint32_t)h->count_tests;
-    HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(Counters), h->stream));
-    HIP_TRY(h, hipEventRecord(h->ev_start, h->stream));
+    if (h->ev_used == h->ev_pool.size()) {
+        if (h->ev_pool.size() >= 4096) {
+            h->ev_used = 0;  // wrap: only the most recent launches are kept
+        } else {
+            hipEvent_t s0 = nullptr, s1 = nullptr;
+            HIP_TRY(h, hipEventCreate(&s0));
+            HIP_TRY(h, hipEventCreate(&s1));
+            h->ev_pool.emplace_back(s0, s1);
+        }
+    }
+    auto& ev = h->ev_pool[h->ev_used++];
+    HIP_TRY(h, hipEventRecord(ev.first, h->stream));
     HIP_TRY(h, launch_render(a, h->stream));
-    HIP_TRY(h, hipEventRecord(h->ev_stop, h->stream));
+    HIP_TRY(h, hipEventRecord(ev.second, h->stream));
     h->timed = true;
+    h->last_spp = params->rays_per_pixel;
     h->last_width = params->width;
     h->last_height = params->height;
     return RT_OK;
@@ -399,8 +417,8 @@ int rt_render_strips(rt_handle* h, const rt_params* params, uint32_t rank, uint3
 
 int rt_assemble_strips(rt_handle* h, const void* gathered_device, uint32_t width, uint32_t height, uint32_t world) {
     if (!h || !gathered_device || world == 0) return fail(h, RT_ERR_INVALID_ARGUMENT, "bad arguments");
-    if ((uint64_t)width * height > (uint64_t)h->max_width * h->max_height)
-        return fail(h, RT_ERR_CAPACITY, "image larger than the size given to rt_create");
+    if ((uint64_t)width * height > h->image_texels)
+        return fail(h, RT_ERR_CAPACITY, "image larger than the bound image buffer");
     HIP_TRY(h, hipSetDevice(h->device));
     unsigned long long pad = rt_strip_texels(width, height, 0, world);
     HIP_TRY(h, launch_assemble((const float4*)gathered_device, h->image, width, height, world, pad, h->stream));
@@ -418,7 +436,7 @@ int rt_synchronize(rt_handle* h) {
 
 int rt_read_image(rt_handle* h, float* out, size_t bytes) {
     if (!h || !out) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
-    if (bytes > (size_t)h->max_width * h->max_height * sizeof(float4))
+    if (bytes > h->image_texels * sizeof(float4))
         return fail(h, RT_ERR_INVALID_ARGUMENT, "read larger than the image");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(out, h->image, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -428,7 +446,7 @@ int rt_read_image(rt_handle* h, float* out, size_t bytes) {
 
 int rt_write_image(rt_handle* h, const float* in, size_t bytes) {
     if (!h || !in) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
-    if (bytes > (size_t)h->max_width * h->max_height * sizeof(float4))
+    if (bytes > h->image_texels * sizeof(float4))
         return fail(h, RT_ERR_INVALID_ARGUMENT, "write larger than the image");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(h->image, in, bytes, hipMemcpyHostToDevice, h->stream));
@@ -444,13 +462,39 @@ int rt_get_stats(rt_handle* h, rt_stats* out) {
     HIP_TRY(h, hipMemcpy(&c, h->counters, sizeof(c), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
     out->segments = c.segments;
-    out->paths = c.paths;
     out->node_tests = c.node_tests;
     out->triangle_tests = c.triangle_tests;
-    if (h->timed) {
+    // counters accumulate over all launches since rt_reset_timing
+    float total = 0.0f;
+    for (size_t i = 0; i < h->ev_used; ++i) {
         float ms = 0.0f;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_start, h->ev_stop));
-        out->kernel_ms = ms;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+        total += ms;
+    }
+    out->kernel_ms = total;
+    out->launches = (uint32_t)h->ev_used;
+    return RT_OK;
+}
+
+int rt_reset_timing(rt_handle* h) {
+    if (!h) return RT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(Counters), h->stream));
+    h->ev_used = 0;
+    return RT_OK;
+}
+
+int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels) {
+    if (!h) return RT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (device_ptr) {
+        h->image = (float4*)device_ptr;
+        h->image_texels = texels;
+    } else {
+        h->image = h->own_image;
+        h->image_texels = (size_t)h->max_width * h->max_height;
     }
     return RT_OK;
 }

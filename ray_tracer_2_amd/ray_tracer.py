@@ -96,6 +96,12 @@ class RayTracer:
     def set_counters(self, enabled):
         self._check(self._L.rt_set_counters(self._h, int(enabled)))
 
+    def reset_timing(self):
+        self._check(self._L.rt_reset_timing(self._h))
+
+    def bind_image(self, device_ptr, texels):
+        self._check(self._L.rt_bind_image(self._h, device_ptr, texels))
+
     def stats(self):
         s = A.Stats()
         self._check(self._L.rt_get_stats(self._h, C.byref(s)))

@@ -45,6 +45,7 @@ def test_debug_views(rt, oracle, loaded, cornell, mode, scale):
 def test_config1_frame(rt, oracle, loaded, cornell, sky):
     """BASELINE config 1 shape: 256x256, 1 spp, 1 bounce, frames = 0."""
     p = rt.make_params(256, 256, 1, 1, skybox=sky, frames=0)
+    loaded.reset_timing()
     loaded.render(p)
     gpu = loaded.read_image(256, 256)
     ref, st = oracle.render(p, cornell)
@@ -73,6 +74,7 @@ def test_config2_sampling_small(rt, oracle, loaded, cornell, shape):
     including ragged sizes that leave partial 8x8 tiles."""
     w, h = shape
     p = rt.make_params(w, h, 4, 8, frames=0)
+    loaded.reset_timing()
     loaded.render(p)
     gpu = loaded.read_image(w, h)
     ref, st = oracle.render(p, cornell)
@@ -85,6 +87,7 @@ def test_counters_match_oracle(rt, oracle, loaded, cornell):
     loaded.set_counters(True)
     try:
         loaded.write_image(np.zeros((72, 128, 4), np.float32))
+        loaded.reset_timing()
         loaded.render(p)
         s = loaded.stats()
     finally:
