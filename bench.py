@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning; default: library default)")
+    ap.add_argument("--blocks", type=int, default=None, help="persistent grid size (tuning)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,6 +96,10 @@ def main():
     arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
     tracer = rt.RayTracer(device=local_rank, max_width=W, max_height=H)
     tracer.load_scene(arrays)
+    if args.variant is not None:
+        tracer.set_option("kernel_variant", args.variant)
+    if args.blocks is not None:
+        tracer.set_option("persistent_blocks", args.blocks)
 
     local_texels = tracer.strip_texels(W, H, rank, world)
     pad_texels = tracer.strip_texels(W, H, 0, world)

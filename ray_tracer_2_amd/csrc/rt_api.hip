@@ -19,6 +19,9 @@ namespace rtd {
 hipError_t launch_render(const RenderArgs& a, hipStream_t stream);
 hipError_t launch_assemble(const float4* gathered, float4* image, uint32_t width, uint32_t height,
                            uint32_t world, unsigned long long pad_texels, hipStream_t stream);
+#if defined(RT_DIAG)
+hipError_t diag_read(unsigned long long* out, bool reset);
+#endif
 }  // namespace rtd
 
 using namespace rtd;
@@ -35,16 +38,17 @@ struct rt_handle {
     uint32_t max_width = 0, max_height = 0;
     float4* image = nullptr;
     Counters* counters = nullptr;
+    uint32_t* work_counters = nullptr;  // ring of per-launch tile counters
+    uint32_t work_slot = 0;
+    int kernel_variant = 0;
+    uint32_t persistent_blocks = 0;
     float* srgb_lut = nullptr;
     // scene
     bool have_scene = false;
-    DMesh* meshes = nullptr;
-    rt_material* mesh_materials = nullptr;
-    float4* nodes = nullptr;
-    float4* tri_isect = nullptr;
-    float4* tri_shade = nullptr;
-    DSphere* spheres = nullptr;
-    rt_material* sphere_materials = nullptr;
+    float4* blob = nullptr;  // the scene, see rt_device.h
+    SceneLayout lay{};
+    bool lds_scene = false;
+    int force_global = 0;  // option "lds_scene" = 0 disables LDS staging (tuning / tests)
     DTexture* textures = nullptr;
     std::vector<uint8_t*> texture_data;
     uint32_t n_meshes = 0, n_spheres = 0, n_textures = 0, n_nodes = 0, n_triangles = 0;
@@ -83,13 +87,7 @@ void free_dev(T*& p) {
 }
 
 void free_scene(rt_handle* h) {
-    free_dev(h->meshes);
-    free_dev(h->mesh_materials);
-    free_dev(h->nodes);
-    free_dev(h->tri_isect);
-    free_dev(h->tri_shade);
-    free_dev(h->spheres);
-    free_dev(h->sphere_materials);
+    free_dev(h->blob);
     h->have_scene = false;
 }
 
@@ -194,6 +192,13 @@ int rt_create(int device_ordinal, uint32_t max_width, uint32_t max_height, rt_ha
     HIP_TRY(h, hipMemsetAsync(h->image, 0, texels * sizeof(float4), h->stream));
     HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(Counters)));
     HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(Counters), h->stream));
+    HIP_TRY(h, hipMalloc((void**)&h->work_counters, 64 * sizeof(uint32_t)));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(h, hipGetDeviceProperties(&prop, device_ordinal));
+        // 4 waves per SIMD (the render kernels' register budget) = 4 workgroups of 4 waves per CU
+        h->persistent_blocks = (uint32_t)prop.multiProcessorCount * 4u;
+    }
     static const float lut[256] = {RT_SRGB_LUT_VALUES};
     HIP_TRY(h, hipMalloc((void**)&h->srgb_lut, sizeof(lut)));
     HIP_TRY(h, hipMemcpyAsync(h->srgb_lut, lut, sizeof(lut), hipMemcpyHostToDevice, h->stream));
@@ -209,6 +214,7 @@ void rt_destroy(rt_handle* h) {
     free_textures(h);
     free_dev(h->own_image);
     free_dev(h->counters);
+    free_dev(h->work_counters);
     free_dev(h->srgb_lut);
     for (auto& e : h->ev_pool) {
         (void)hipEventDestroy(e.first);
@@ -235,37 +241,98 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
     HIP_TRY(h, hipSetDevice(h->device));
 
     try {
-        // Derived per-mesh data + validation.
-        std::vector<DMesh> dm(n_meshes);
-        std::vector<rt_material> mm(n_meshes);
+        // ---- validation + wide BVH records ---------------------------------
+        struct WideRec { float4 q[4]; };
+        std::vector<WideRec> wide;
+        std::vector<uint32_t> wide_base(n_meshes), root_idx(n_meshes), root_count(n_meshes);
+        std::vector<uint32_t> wide_index(n_nodes, 0xffffffffu);  // per original node
         uint32_t max_height = 0;
         for (uint32_t i = 0; i < n_meshes; ++i) {
             const rt_mesh_uniform& m = meshes[i];
-            DMesh& d = dm[i];
-            memcpy(d.w2m, m.world_to_model, 64);
-            memcpy(d.m2w, m.model_to_world, 64);
-            d.node_offset = m.node_offset;
-            d.tri_offset = m.triangle_offset;
-            d.flags = 0;
-            if (i > 0 && memcmp(m.world_to_model, meshes[i - 1].world_to_model, 64) == 0) d.flags |= DMESH_SAME_XFORM;
-            if (m.material.flag == RT_MATERIAL_GLASS) d.flags |= DMESH_GLASS;
             uint32_t height = 0;
             std::string why;
             int rc = mesh_bvh_height(nodes, n_nodes, m.node_offset, m.triangle_offset, n_triangles, height, why);
             if (rc != RT_OK) return fail(h, rc, "mesh " + std::to_string(i) + ": " + why);
             // The shader's stack holds 32 entries (wgsl:297); with the near
-            // child kept in a register this kernel needs `height` entries and
+            // child kept in registers this kernel needs `height` entries and
             // the shader height + 1.  Deeper trees overflow the shader's
             // stack (undefined clamped behaviour) and are rejected.
             if (height + 1 > RT_BVH_STACK)
                 return fail(h, RT_ERR_BVH_DEPTH, "mesh " + std::to_string(i) + ": BVH deeper than the 32-entry traversal stack");
             if (height > max_height) max_height = height;
-            d.root_count = nodes[m.node_offset].count;
-            mm[i] = m.material;
+            // Wide records: internal nodes in DFS pre-order, indexed per mesh.
+            // (Meshes may alias node ranges; records are built per mesh.)
+            wide_base[i] = (uint32_t)wide.size();
+            const rt_node* mn = nodes + m.node_offset;
+            if (mn[0].count > 0) {
+                root_idx[i] = mn[0].first;
+                root_count[i] = mn[0].count;
+                continue;
+            }
+            root_idx[i] = 0;
+            root_count[i] = 0;
+            std::vector<uint32_t> order;  // original mesh-local indices of internal nodes, pre-order
+            std::vector<uint32_t> st{0u};
+            while (!st.empty()) {
+                uint32_t n = st.back();
+                st.pop_back();
+                wide_index[m.node_offset + n] = (uint32_t)order.size();
+                order.push_back(n);
+                if (mn[mn[n].right].count == 0) st.push_back(mn[n].right);
+                if (mn[mn[n].left].count == 0) st.push_back(mn[n].left);
+            }
+            for (uint32_t n : order) {
+                const rt_node &ca = mn[mn[n].left], &cb = mn[mn[n].right];
+                auto kind = [&](const rt_node& c, uint32_t local, uint32_t& idx, uint32_t& cnt) {
+                    if (c.count > 0) {
+                        idx = c.first;
+                        cnt = c.count;
+                    } else {
+                        idx = wide_index[m.node_offset + local];
+                        cnt = 0;
+                    }
+                };
+                uint32_t ai, ac, bi, bc;
+                kind(ca, mn[n].left, ai, ac);
+                kind(cb, mn[n].right, bi, bc);
+                auto asf = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+                WideRec w;
+                w.q[0] = make_float4(ca.aabb_min[0], ca.aabb_min[1], ca.aabb_min[2], asf(ai));
+                w.q[1] = make_float4(ca.aabb_max[0], ca.aabb_max[1], ca.aabb_max[2], asf(ac));
+                w.q[2] = make_float4(cb.aabb_min[0], cb.aabb_min[1], cb.aabb_min[2], asf(bi));
+                w.q[3] = make_float4(cb.aabb_max[0], cb.aabb_max[1], cb.aabb_max[2], asf(bc));
+                wide.push_back(w);
+            }
         }
+        // ---- blob layout ------------------------------------------------------
+        SceneLayout lay{};
+        uint64_t off = 0;
+        lay.mesh_off = (uint32_t)off;   off += (uint64_t)n_meshes * MESH_REC_BYTES;
+        lay.wide_off = (uint32_t)off;   off += (uint64_t)wide.size() * WIDE_REC_BYTES;
+        lay.tri_off = (uint32_t)off;    off += (uint64_t)n_triangles * TRI_ISECT_BYTES;
+        lay.shade_off = (uint32_t)off;  off += (uint64_t)n_triangles * TRI_SHADE_BYTES;
+        lay.mat_off = (uint32_t)off;    off += (uint64_t)(n_meshes + n_spheres) * MATERIAL_BYTES;
+        lay.sphere_off = (uint32_t)off; off += (uint64_t)n_spheres * SPHERE_BYTES;
+        if (off == 0) off = 16;
+        if (off > 0xfffffff0ull) return fail(h, RT_ERR_CAPACITY, "scene larger than 4 GiB");
+        lay.bytes = (uint32_t)off;
+        std::vector<float4> blob(off / 16, make_float4(0, 0, 0, 0));
+        auto asf = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+        for (uint32_t i = 0; i < n_meshes; ++i) {
+            const rt_mesh_uniform& m = meshes[i];
+            float4* r = blob.data() + (lay.mesh_off + (size_t)i * MESH_REC_BYTES) / 16;
+            memcpy(r, m.world_to_model, 64);
+            memcpy(r + 4, m.model_to_world, 64);
+            uint32_t flags = 0;
+            if (i > 0 && memcmp(m.world_to_model, meshes[i - 1].world_to_model, 64) == 0) flags |= DMESH_SAME_XFORM;
+            if (m.material.flag == RT_MATERIAL_GLASS) flags |= DMESH_GLASS;
+            r[8] = make_float4(asf(flags), asf(root_idx[i]), asf(root_count[i]), asf(m.triangle_offset));
+            r[9] = make_float4(asf(wide_base[i]), 0.0f, 0.0f, 0.0f);
+            memcpy(blob.data() + (lay.mat_off + (size_t)i * MATERIAL_BYTES) / 16, &m.material, MATERIAL_BYTES);
+        }
+        if (!wide.empty()) memcpy(blob.data() + lay.wide_off / 16, wide.data(), wide.size() * sizeof(WideRec));
         // Triangle re-layout (see rt_device.h).  The subtractions and the
         // cross product are wgsl:261-263, evaluated once here in binary32.
-        std::vector<float4> ti((size_t)n_triangles * 3), ts((size_t)n_triangles * 4);
         for (uint32_t t = 0; t < n_triangles; ++t) {
             const rt_packed_triangle& p = triangles[t];
             float abx = p.v2[0] - p.v1[0], aby = p.v2[1] - p.v1[1], abz = p.v2[2] - p.v1[2];
@@ -273,37 +340,36 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             float nx = aby * acz - abz * acy;
             float ny = abz * acx - abx * acz;
             float nz = abx * acy - aby * acx;
-            ti[(size_t)t * 3 + 0] = make_float4(p.v1[0], p.v1[1], p.v1[2], nx);
-            ti[(size_t)t * 3 + 1] = make_float4(abx, aby, abz, ny);
-            ti[(size_t)t * 3 + 2] = make_float4(acx, acy, acz, nz);
-            ts[(size_t)t * 4 + 0] = make_float4(p.n1[0], p.n1[1], p.n1[2], p.uv10);
-            ts[(size_t)t * 4 + 1] = make_float4(p.n2[0], p.n2[1], p.n2[2], p.uv11);
-            ts[(size_t)t * 4 + 2] = make_float4(p.n3[0], p.n3[1], p.n3[2], p.uv20);
-            ts[(size_t)t * 4 + 3] = make_float4(p.uv21, p.uv30, p.uv31, 0.0f);
+            float4* ti = blob.data() + (lay.tri_off + (size_t)t * TRI_ISECT_BYTES) / 16;
+            ti[0] = make_float4(p.v1[0], p.v1[1], p.v1[2], nx);
+            ti[1] = make_float4(abx, aby, abz, ny);
+            ti[2] = make_float4(acx, acy, acz, nz);
+            float4* ts = blob.data() + (lay.shade_off + (size_t)t * TRI_SHADE_BYTES) / 16;
+            ts[0] = make_float4(p.n1[0], p.n1[1], p.n1[2], p.uv10);
+            ts[1] = make_float4(p.n2[0], p.n2[1], p.n2[2], p.uv11);
+            ts[2] = make_float4(p.n3[0], p.n3[1], p.n3[2], p.uv20);
+            ts[3] = make_float4(p.uv21, p.uv30, p.uv31, 0.0f);
         }
-        std::vector<DSphere> ds(n_spheres);
-        std::vector<rt_material> sm(n_spheres);
         for (uint32_t i = 0; i < n_spheres; ++i) {
-            ds[i] = DSphere{spheres[i].pos[0], spheres[i].pos[1], spheres[i].pos[2], spheres[i].radius};
-            sm[i] = spheres[i].material;
+            blob[(lay.sphere_off + (size_t)i * SPHERE_BYTES) / 16] =
+                make_float4(spheres[i].pos[0], spheres[i].pos[1], spheres[i].pos[2], spheres[i].radius);
+            memcpy(blob.data() + (lay.mat_off + (size_t)(n_meshes + i) * MATERIAL_BYTES) / 16,
+                   &spheres[i].material, MATERIAL_BYTES);
         }
 
         free_scene(h);
         int rc;
-        if ((rc = upload(h, h->meshes, dm.data(), dm.size())) != RT_OK) return rc;
-        if ((rc = upload(h, h->mesh_materials, mm.data(), mm.size())) != RT_OK) return rc;
-        static_assert(sizeof(rt_node) == 3 * sizeof(float4), "node layout");
-        if ((rc = upload(h, h->nodes, reinterpret_cast<const float4*>(nodes), (size_t)n_nodes * 3)) != RT_OK) return rc;
-        if ((rc = upload(h, h->tri_isect, ti.data(), ti.size())) != RT_OK) return rc;
-        if ((rc = upload(h, h->tri_shade, ts.data(), ts.size())) != RT_OK) return rc;
-        if ((rc = upload(h, h->spheres, ds.data(), ds.size())) != RT_OK) return rc;
-        if ((rc = upload(h, h->sphere_materials, sm.data(), sm.size())) != RT_OK) return rc;
+        if ((rc = upload(h, h->blob, blob.data(), blob.size())) != RT_OK) return rc;
         HIP_TRY(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
+        h->lay = lay;
         h->n_meshes = n_meshes;
         h->n_spheres = n_spheres;
         h->n_nodes = n_nodes;
         h->n_triangles = n_triangles;
         h->stack_entries = max_height ? max_height : 1;
+        // LDS residency: blob + the four waves' stacks within the per-workgroup budget
+        uint64_t stacks = (uint64_t)h->stack_entries * 128u * sizeof(uint32_t) * WAVES_PER_BLOCK;
+        h->lds_scene = (uint64_t)lay.bytes + stacks <= LDS_BUDGET_BYTES;
         h->camera = scene->camera;
         h->have_scene = true;
     } catch (const std::bad_alloc&) {
@@ -343,6 +409,23 @@ int rt_set_camera(rt_handle* h, const rt_camera_uniform* camera) {
     return RT_OK;
 }
 
+int rt_set_option(rt_handle* h, const char* name, int value) {
+    if (!h || !name) return RT_ERR_INVALID_ARGUMENT;
+    std::string n(name);
+    if (n == "kernel_variant") {
+        if (value < 0 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "kernel_variant must be 0 or 1");
+        h->kernel_variant = value;
+    } else if (n == "persistent_blocks") {
+        if (value < 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "persistent_blocks must be >= 1");
+        h->persistent_blocks = (uint32_t)value;
+    } else if (n == "lds_scene") {
+        h->force_global = value ? 0 : 1;
+    } else {
+        return fail(h, RT_ERR_INVALID_ARGUMENT, "unknown option " + n);
+    }
+    return RT_OK;
+}
+
 int rt_set_counters(rt_handle* h, int enabled) {
     if (!h) return RT_ERR_INVALID_ARGUMENT;
     h->count_tests = enabled ? 1 : 0;
@@ -361,19 +444,17 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     if (!h->have_scene) return fail(h, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
     if (world == 0 || rank >= world) return fail(h, RT_ERR_INVALID_ARGUMENT, "bad rank/world");
     if (params->width == 0 || params->height == 0) return fail(h, RT_ERR_INVALID_ARGUMENT, "empty image");
-    if (rt_strip_texels(params->width, params->height, rank, world) > h->image_texels)
+    const uint64_t need_texels = world == 1 ? (uint64_t)params->width * params->height
+                                            : rt_strip_texels(params->width, params->height, rank, world);
+    if (need_texels > h->image_texels)
         return fail(h, RT_ERR_CAPACITY, "image larger than the bound image buffer");
     HIP_TRY(h, hipSetDevice(h->device));
     RenderArgs a{};
     a.params = *params;
     a.camera = h->camera;
-    a.meshes = h->meshes;
-    a.mesh_materials = h->mesh_materials;
-    a.nodes = h->nodes;
-    a.tri_isect = h->tri_isect;
-    a.tri_shade = h->tri_shade;
-    a.spheres = h->spheres;
-    a.sphere_materials = h->sphere_materials;
+    a.blob = h->blob;
+    a.lay = h->lay;
+    a.lds_scene = (h->lds_scene && !h->force_global) ? 1u : 0u;
     a.textures = h->textures;
     a.srgb_lut = h->srgb_lut;
     a.image = h->image;
@@ -388,6 +469,12 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     uint32_t strips = (params->height + 7) / 8;
     a.tiles_y = strips / world + (rank < strips % world ? 1 : 0);
     a.count_tests = (uint32_t)h->count_tests;
+    a.kernel_variant = (uint32_t)h->kernel_variant;
+    a.persistent_blocks = h->persistent_blocks;
+    // a fresh tile counter per launch (ring of 64: launches on one stream are ordered)
+    h->work_slot = (h->work_slot + 1) & 63u;
+    a.work_counter = h->work_counters + h->work_slot;
+    HIP_TRY(h, hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), h->stream));
     if (h->ev_used == h->ev_pool.size()) {
         if (h->ev_pool.size() >= 4096) {
             h->ev_used = 0;  // wrap: only the most recent launches are kept
@@ -498,6 +585,16 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels) {
     }
     return RT_OK;
 }
+
+#if defined(RT_DIAG)
+int rt_diag_read(rt_handle* h, unsigned long long* out64, int reset) {
+    if (!h || !out64) return RT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, rtd::diag_read(out64, reset != 0));
+    return RT_OK;
+}
+#endif
 
 void* rt_device_image(rt_handle* h) { return h ? (void*)h->image : nullptr; }
 void* rt_stream(rt_handle* h) { return h ? (void*)h->stream : nullptr; }

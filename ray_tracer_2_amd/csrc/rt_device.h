@@ -13,34 +13,52 @@
 
 namespace rtd {
 
-// Per-mesh record.  Matrices keep rows 0..2 of each column (the shader only
-// takes .xyz of mat4 * vec4): m[col*4 + row], row 3 unused.
-struct alignas(16) DMesh {
-    float w2m[16];
-    float m2w[16];
-    uint32_t node_offset;
-    uint32_t tri_offset;
-    uint32_t flags;  // DMESH_*
-    uint32_t root_count;  // nodes[node_offset].count (0 => internal root)
+// The whole scene is one blob of 16-byte words, either read in place (global
+// memory: uniform reads become scalar loads) or, when it fits the LDS budget,
+// staged into LDS once per workgroup with coalesced 16-byte loads.  All
+// offsets below are byte offsets into that blob.
+struct SceneLayout {
+    uint32_t mesh_off;    // MESH_REC_BYTES per mesh
+    uint32_t wide_off;    // WIDE_REC_BYTES per internal BVH node
+    uint32_t tri_off;     // TRI_ISECT_BYTES per triangle
+    uint32_t shade_off;   // TRI_SHADE_BYTES per triangle
+    uint32_t mat_off;     // 96 B rt_material per mesh, then per sphere
+    uint32_t sphere_off;  // 16 B (centre, radius) per sphere
+    uint32_t bytes;       // total, multiple of 16
+    uint32_t _pad;
 };
+
+// Mesh record, 10 x 16 B:
+//   q0..q3  world_to_model columns   q4..q7  model_to_world columns
+//   q8 = (flags, root_idx, root_count, tri_base)   q9 = (wide_base, 0, 0, 0)
+// root_count > 0: the root is a leaf with triangles [root_idx, root_idx+count);
+// root_count == 0: root_idx is the mesh-local index of its wide record.
+constexpr uint32_t MESH_REC_BYTES = 160;
 enum : uint32_t {
     DMESH_SAME_XFORM = 1u,  // world_to_model bit-identical to the previous mesh's
     DMESH_GLASS = 2u,       // material.flag == GLASS  => no backface culling (wgsl:375)
 };
+// Wide BVH record of one internal node (both children's boxes inline, so a
+// visit is one round trip instead of three dependent ones), 4 x 16 B:
+//   q0 = (a.min, a_idx) q1 = (a.max, a_count) q2 = (b.min, b_idx) q3 = (b.max, b_count)
+// child leaf: idx = first triangle (mesh-local), count > 0;
+// child internal: idx = mesh-local wide index, count = 0.
+constexpr uint32_t WIDE_REC_BYTES = 64;
+// Triangle intersection record, 3 x 16 B:
+//   q0 = (v1.xyz, n.x) q1 = (edge_ab.xyz, n.y) q2 = (edge_ac.xyz, n.z)
+//   with edge_ab = v2 - v1, edge_ac = v3 - v1, n = cross(edge_ab, edge_ac)
+//   exactly as wgsl:261-263 computes them per test.
+constexpr uint32_t TRI_ISECT_BYTES = 48;
+// Triangle shading record, 4 x 16 B:
+//   q0 = (n1.xyz, u10) q1 = (n2.xyz, u11) q2 = (n3.xyz, u20) q3 = (u21, u30, u31, 0)
+constexpr uint32_t TRI_SHADE_BYTES = 64;
+constexpr uint32_t MATERIAL_BYTES = 96;
+constexpr uint32_t SPHERE_BYTES = 16;
 
-// BVH node, 48 B = 3 x float4, unchanged from rt_node:
-//   q0 = (left, right, first, count) as bits, q1 = (min.xyz, -), q2 = (max.xyz, -)
-//
-// Triangle, split in two 48-B records:
-//   isect: q0 = (v1.xyz, n.x) q1 = (edge_ab.xyz, n.y) q2 = (edge_ac.xyz, n.z)
-//          with edge_ab = v2 - v1, edge_ac = v3 - v1, n = cross(edge_ab,
-//          edge_ac) exactly as wgsl:261-263 computes them per test
-//   shade: q0 = (n1.xyz, uv10) q1 = (n2.xyz, uv11)... see pack in rt_api.hip:
-//          q0 = (n1.xyz, u10) q1 = (n2.xyz, u11) q2 = (n3.xyz, u20) and
-//          q3 = (u21, u30, u31, 0)  -> 64 B
-struct alignas(16) DSphere {
-    float cx, cy, cz, radius;
-};
+// LDS budget per 256-thread workgroup (4 workgroups per CU share 160 KiB).
+constexpr uint32_t LDS_BUDGET_BYTES = 40 * 1024;
+constexpr uint32_t BLOCK_THREADS = 256;
+constexpr uint32_t WAVES_PER_BLOCK = BLOCK_THREADS / 64;
 
 struct DTexture {
     const uint8_t* rgba8;
@@ -58,22 +76,21 @@ struct Counters {
 struct RenderArgs {
     rt_params params;
     rt_camera_uniform camera;
-    const DMesh* meshes;
-    const rt_material* mesh_materials;
-    const float4* nodes;      // 3 float4 per node
-    const float4* tri_isect;  // 3 float4 per triangle
-    const float4* tri_shade;  // 4 float4 per triangle
-    const DSphere* spheres;
-    const rt_material* sphere_materials;
+    const float4* blob;  // the scene, see SceneLayout
+    SceneLayout lay;
     const DTexture* textures;
     const float* srgb_lut;
     float4* image;  // full frame, or compact strips when strip_world > 1
     Counters* counters;
+    uint32_t* work_counter;  // persistent kernel: next 8x8 tile to hand out (zeroed per launch)
     uint32_t n_meshes, n_spheres, n_textures;
-    uint32_t stack_entries;  // per-lane BVH stack depth (LDS dwords per lane)
+    uint32_t stack_entries;  // per-lane BVH stack depth
     uint32_t strip_rank, strip_world;
     uint32_t tiles_x, tiles_y;  // 8x8 tiles of the (local) image
     uint32_t count_tests;       // 1 => accumulate node/triangle test counters
+    uint32_t kernel_variant;    // 0 = persistent waves + lane refill, 1 = one wave per tile
+    uint32_t persistent_blocks; // grid size of the persistent kernel
+    uint32_t lds_scene;         // 1 => the blob is staged into LDS
 };
 
 }  // namespace rtd

@@ -2,21 +2,25 @@
 // per-pixel path-trace loop of shaders/ray_tracer.wgsl (reference).
 //
 // Mapping to CDNA4
-//   * one lane per pixel, one 64-lane wavefront per 8x8 pixel tile (the
-//     reference's @workgroup_size(8,8), wgsl:145); a block is one wave.
-//   * blockIdx -> tile mapping is XCD-aware: consecutive tiles go to the same
-//     XCD so neighbouring tiles share that XCD's L2 (matters once the BVH no
-//     longer fits L1).
-//   * the mesh loop (wgsl:369) is wave-uniform: mesh records, root nodes and
-//     the triangles of root-leaf meshes are read through scalar loads (SGPR
-//     operands), only diverged BVH levels use per-lane vector loads.
-//   * per-lane BVH stacks live in LDS, lane-interleaved (entry k of lane l at
-//     dword k*64 + l: conflict-free), with the near child kept in a register.
+//   * one lane per pixel; a wavefront starts on one 8x8 pixel tile (the
+//     reference's @workgroup_size(8,8), wgsl:145); workgroups are 4 waves.
+//   * the scene (mesh records, BVH, triangles, materials) is one blob of
+//     16-byte words (rt_device.h).  When it fits the LDS budget every
+//     workgroup stages it into LDS once with coalesced 16-byte loads and all
+//     traversal reads are LDS reads (~64 cycles instead of an L1/L2 round
+//     trip); otherwise it is read in place and wave-uniform reads (the mesh
+//     loop, wgsl:369, root-leaf triangles) become scalar loads.
+//   * BVH internal nodes are re-laid-out "wide": both children's boxes and
+//     kinds sit in the parent's 64-byte record, so a node visit is one memory
+//     round trip, not three dependent ones.
+//   * per-lane BVH stacks live in LDS, lane-interleaved (conflict-free), with
+//     the near child kept in registers.
 //   * a path is a small state machine (ray generation / segment / shading) so
-//     lanes whose path ended start their pixel's next sample at once instead
-//     of idling until the longest path of the wave ends.  The samples of one
-//     pixel share one sequential RNG stream (wgsl:475,487-497), so they
-//     cannot be spread over lanes.
+//     lanes whose path ended start their pixel's next sample at once; the
+//     persistent variant refills finished lanes with new pixels using
+//     __ballot + mbcnt prefix counts.  The samples of one pixel share one
+//     sequential RNG stream (wgsl:475,487-497) and stay on one lane.
+//   * blockIdx -> tile mapping of the tile variant is XCD-aware.
 //   * MFMA is deliberately unused: there is no dense contraction here.
 //
 // Arithmetic contract: every floating-point operation below is the IEEE
@@ -36,6 +40,27 @@ namespace rtd {
 namespace {
 
 #define DEV __device__ __forceinline__
+
+// waves per SIMD the render kernels are compiled for (register budget 512 / N)
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 4
+#endif
+
+// Diagnostic build only (-DRT_DIAG=1, tools/diag.py): per-section wave visits
+// and active-lane sums, to price divergence.  Compiled out of the product.
+#if defined(RT_DIAG)
+__device__ unsigned long long g_diag[64];
+#define DIAG(id)                                                                  \
+    do {                                                                          \
+        unsigned long long m_ = __ballot(1);                                      \
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m_)) {               \
+            atomicAdd(&g_diag[2 * (id)], 1ull);                                   \
+            atomicAdd(&g_diag[2 * (id) + 1], (unsigned long long)__popcll(m_));   \
+        }                                                                         \
+    } while (0)
+#else
+#define DIAG(id) do { } while (0)
+#endif
 
 struct f3 {
     float x, y, z;
@@ -118,6 +143,40 @@ DEV void rand_in_unit_disk(uint32_t& s, float& ox, float& oy) {
     oy = sn * r;
 }
 
+// ---- scene memory ----------------------------------------------------------
+extern __shared__ float4 lds_mem[];
+
+template <bool LDS>
+DEV float4 ld4(const RenderArgs& a, uint32_t byte_off) {
+    if constexpr (LDS) {
+        return lds_mem[byte_off >> 4];
+    } else {
+        return a.blob[byte_off >> 4];
+    }
+}
+template <bool LDS>
+DEV float ldf(const RenderArgs& a, uint32_t byte_off) {
+    if constexpr (LDS) {
+        return reinterpret_cast<const float*>(lds_mem)[byte_off >> 2];
+    } else {
+        return reinterpret_cast<const float*>(a.blob)[byte_off >> 2];
+    }
+}
+template <bool LDS>
+DEV int ldi(const RenderArgs& a, uint32_t byte_off) {
+    return __float_as_int(ldf<LDS>(a, byte_off));
+}
+DEV uint32_t fbits(float f) { return __float_as_uint(f); }
+
+// (mat4 * vec4(v, w)).xyz with the four columns as float4
+DEV f3 mat_cols_xyz(float4 c0, float4 c1, float4 c2, float4 c3, f3 v, float w) {
+    f3 r;
+    r.x = ((c0.x * v.x + c1.x * v.y) + c2.x * v.z) + c3.x * w;
+    r.y = ((c0.y * v.x + c1.y * v.y) + c2.y * v.z) + c3.y * w;
+    r.z = ((c0.z * v.x + c1.z * v.y) + c2.z * v.z) + c3.z * w;
+    return r;
+}
+
 // ---- intersection ---------------------------------------------------------
 struct MeshBest {  // closest triangle hit inside the mesh being traversed
     float t, u, v, w, det;
@@ -127,15 +186,21 @@ struct MeshBest {  // closest triangle hit inside the mesh being traversed
 // wgsl:258-290 against the pre-laid-out record (rt_device.h): edge_ab, edge_ac
 // and their cross product are the same IEEE operations wgsl:261-263 evaluate,
 // hoisted to upload time.  Shading outputs are deferred to the winner.
+template <int SEC>
 DEV void tri_test(f3 lo, f3 ld, float4 q0, float4 q1, float4 q2, bool cull, uint32_t idx,
                   MeshBest& b) {
-    f3 v1{q0.x, q0.y, q0.z}, n{q0.w, q1.w, q2.w};
-    f3 eab{q1.x, q1.y, q1.z}, eac{q2.x, q2.y, q2.z};
-    f3 ao = lo - v1;
-    f3 dao = cross3(ao, ld);
+    DIAG(SEC);
+    f3 n{q0.w, q1.w, q2.w};
+    // The determinant only needs the ray direction and the (hoisted) normal:
+    // evaluate it first so culled triangles cost five operations.
     float det = -dot3(ld, n);
     bool keep = cull ? (det >= 1e-8f) : (rtm::abs_(det) >= 1e-8f);
     if (keep) {
+        DIAG(SEC + 1);
+        f3 v1{q0.x, q0.y, q0.z};
+        f3 eab{q1.x, q1.y, q1.z}, eac{q2.x, q2.y, q2.z};
+        f3 ao = lo - v1;
+        f3 dao = cross3(ao, ld);
         float inv = 1.0f / det;
         float dst = dot3(ao, n) * inv;
         float u = dot3(eac, dao) * inv;
@@ -162,64 +227,72 @@ DEV float aabb_dist(f3 lo, f3 inv, float4 bmin, float4 bmax, float t) {
     return did_hit ? t_near : INF;
 }
 
-// wgsl:292-335 for one mesh.  `stack` points at this lane's LDS column
-// (stride 64 dwords).  Visit order per lane is the shader's: far child
-// pushed, near child visited next (kept in a register instead of a push/pop
-// pair), nodes popped without re-testing.
-template <bool STATS>
-DEV void traverse_mesh(const RenderArgs& a, const DMesh* __restrict__ m, f3 lo, f3 ld, f3 inv,
-                       uint32_t* stack, MeshBest& best, int& node_tests, int& tri_tests) {
-    const float4* __restrict__ nodes = a.nodes + (size_t)m->node_offset * 3;
-    const float4* __restrict__ tris = a.tri_isect + (size_t)m->tri_offset * 3;
-    const bool cull = (m->flags & DMESH_GLASS) == 0;
-    const uint32_t root_count = m->root_count;
+// wgsl:292-335 for one mesh.  A traversal entry is (idx, count): count > 0 is
+// a leaf holding triangles [idx, idx + count), count == 0 is the internal node
+// whose wide record has mesh-local index idx.  `stack` points at this lane's
+// LDS column (stride 64 dwords, two dwords per entry).  Visit order per lane
+// is the shader's: far child pushed, near child visited next (kept in
+// registers instead of a push/pop pair), entries popped without re-testing.
+// "while-while": a lane first descends through internal nodes until it holds a
+// leaf, then the wave tests leaf triangles together.
+template <bool LDS, bool STATS>
+DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_count, uint32_t tri_base,
+                       uint32_t wide_base, bool cull, f3 lo, f3 ld, f3 inv, uint32_t* stack,
+                       MeshBest& best, int& node_tests, int& tri_tests) {
+    const uint32_t tri0 = a.lay.tri_off + tri_base * TRI_ISECT_BYTES;
     if (root_count > 0) {
-        // Root is a leaf: every lane tests the same triangles (uniform
-        // addresses -> scalar loads).
-        const uint32_t first = __float_as_uint(nodes[0].z);
+        // Root is a leaf: every lane tests the same triangles (uniform reads).
         if (STATS) tri_tests += (int)root_count;
         for (uint32_t j = 0; j < root_count; ++j) {
-            const float4* t = tris + (size_t)(first + j) * 3;
-            tri_test(lo, ld, t[0], t[1], t[2], cull, first + j, best);
+            const uint32_t t = tri0 + (root_idx + j) * TRI_ISECT_BYTES;
+            tri_test<4>(lo, ld, ld4<LDS>(a, t), ld4<LDS>(a, t + 16), ld4<LDS>(a, t + 32), cull, root_idx + j, best);
         }
         return;
     }
-    uint32_t cur = 0, sp = 0;
+    const uint32_t wide0 = a.lay.wide_off + wide_base * WIDE_REC_BYTES;
+    uint32_t cur = root_idx, cur_count = 0, sp = 0;
     for (;;) {
-        const float4 h = nodes[(size_t)cur * 3];
-        const uint32_t count = __float_as_uint(h.w);
-        if (count > 0) {
-            const uint32_t first = __float_as_uint(h.z);
-            if (STATS) tri_tests += (int)count;
-            for (uint32_t j = 0; j < count; ++j) {
-                const float4* t = tris + (size_t)(first + j) * 3;
-                tri_test(lo, ld, t[0], t[1], t[2], cull, first + j, best);
-            }
-            if (sp == 0) break;
-            --sp;
-            cur = stack[sp * 64];
-        } else {
-            const uint32_t ia = __float_as_uint(h.x), ib = __float_as_uint(h.y);
-            const float4* na = nodes + (size_t)ia * 3;
-            const float4* nb = nodes + (size_t)ib * 3;
-            float da = aabb_dist(lo, inv, na[1], na[2], best.t);
-            float db = aabb_dist(lo, inv, nb[1], nb[2], best.t);
+        bool finished = false;
+        while (cur_count == 0) {
+            DIAG(7);
+            const uint32_t wo = wide0 + cur * WIDE_REC_BYTES;
+            const float4 q0 = ld4<LDS>(a, wo), q1 = ld4<LDS>(a, wo + 16), q2 = ld4<LDS>(a, wo + 32),
+                         q3 = ld4<LDS>(a, wo + 48);
+            float da = aabb_dist(lo, inv, q0, q1, best.t);
+            float db = aabb_dist(lo, inv, q2, q3, best.t);
             if (STATS) node_tests += 2;
-            bool left_closer = da < db;
-            float near_d = left_closer ? da : db, far_d = left_closer ? db : da;
-            uint32_t near_i = left_closer ? ia : ib, far_i = left_closer ? ib : ia;
+            const bool left_closer = da < db;
+            const float near_d = left_closer ? da : db, far_d = left_closer ? db : da;
+            const uint32_t near_i = fbits(left_closer ? q0.w : q2.w), near_c = fbits(left_closer ? q1.w : q3.w);
+            const uint32_t far_i = fbits(left_closer ? q2.w : q0.w), far_c = fbits(left_closer ? q3.w : q1.w);
             if (far_d < best.t) {
-                stack[sp * 64] = far_i;
+                stack[sp * 128] = far_i;
+                stack[sp * 128 + 64] = far_c;
                 ++sp;
             }
             if (near_d < best.t) {
                 cur = near_i;
+                cur_count = near_c;
             } else {
-                if (sp == 0) break;
+                if (sp == 0) {
+                    finished = true;
+                    break;
+                }
                 --sp;
-                cur = stack[sp * 64];
+                cur = stack[sp * 128];
+                cur_count = stack[sp * 128 + 64];
             }
         }
+        if (finished) break;
+        if (STATS) tri_tests += (int)cur_count;
+        for (uint32_t j = 0; j < cur_count; ++j) {
+            const uint32_t t = tri0 + (cur + j) * TRI_ISECT_BYTES;
+            tri_test<8>(lo, ld, ld4<LDS>(a, t), ld4<LDS>(a, t + 16), ld4<LDS>(a, t + 32), cull, cur + j, best);
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = stack[sp * 128];
+        cur_count = stack[sp * 128 + 64];
     }
 }
 
@@ -229,27 +302,27 @@ struct Hit {
     f3 point, normal;
     float u, v;       // texture coordinates
     bool backface;
-    int object;       // >= 0: mesh index, < 0: sphere -(index) - 1
+    uint32_t mat_off; // byte offset of the winner's material in the blob
 };
 
 // wgsl:353-396 (+ ray_sphere :223-256).  Per-object outputs that only the
 // overall winner needs (normals, uv) are computed once after the loops from
 // the same inputs, which yields the same bits.
-template <bool STATS>
+template <bool LDS, bool STATS>
 DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int& node_tests,
                         int& tri_tests) {
     float closest = INF;
-    int object = 0;
+    int object = 0;  // >= 0 mesh index, < 0 sphere -(index) - 1
     bool any = false;
     // spheres
     float s_dst = 0.0f;
     bool s_inside = false;
     for (uint32_t i = 0; i < a.n_spheres; ++i) {
-        const DSphere sp = a.spheres[i];
-        f3 oc = ro - f3{sp.cx, sp.cy, sp.cz};
+        const float4 sp = ld4<LDS>(a, a.lay.sphere_off + i * SPHERE_BYTES);
+        f3 oc = ro - f3{sp.x, sp.y, sp.z};
         float qa = dot3(rd, rd);
         float qb = 2.0f * dot3(oc, rd);
-        float qc = dot3(oc, oc) - sp.radius * sp.radius;
+        float qc = dot3(oc, oc) - sp.w * sp.w;
         float disc = qb * qb - (4.0f * qa) * qc;
         if (disc >= 0.0f) {
             float s = rtm::sqrt_(disc);
@@ -273,21 +346,31 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
     MeshBest win{};  // winner's triangle data
     f3 win_point{0, 0, 0};
     for (uint32_t i = 0; i < a.n_meshes; ++i) {
-        const DMesh* __restrict__ m = a.meshes + i;
-        if ((m->flags & DMESH_SAME_XFORM) == 0) {
+        const uint32_t mo = a.lay.mesh_off + i * MESH_REC_BYTES;
+        const float4 hdr = ld4<LDS>(a, mo + 128);
+        const uint32_t flags = fbits(hdr.x);
+        if ((flags & DMESH_SAME_XFORM) == 0) {
+            DIAG(3);
             // identical matrix => identical local ray: reuse (same bits)
-            lo = mat_xyz(m->w2m, ro, 1.0f);
-            ld = normalize3(mat_xyz(m->w2m, rd, 0.0f));
+            const float4 c0 = ld4<LDS>(a, mo), c1 = ld4<LDS>(a, mo + 16), c2 = ld4<LDS>(a, mo + 32),
+                         c3 = ld4<LDS>(a, mo + 48);
+            lo = mat_cols_xyz(c0, c1, c2, c3, ro, 1.0f);
+            ld = normalize3(mat_cols_xyz(c0, c1, c2, c3, rd, 0.0f));
             inv = f3{1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z};
         }
         MeshBest b;
         b.t = INF;
         b.tri = 0xffffffffu;
         b.u = b.v = b.w = b.det = 0.0f;
-        traverse_mesh<STATS>(a, m, lo, ld, inv, stack, b, node_tests, tri_tests);
+        const uint32_t wide_base = fbits(ld4<LDS>(a, mo + 144).x);
+        traverse_mesh<LDS, STATS>(a, fbits(hdr.y), fbits(hdr.z), fbits(hdr.w), wide_base,
+                                  (flags & DMESH_GLASS) == 0, lo, ld, inv, stack, b, node_tests, tri_tests);
         if (b.tri != 0xffffffffu) {
+            DIAG(10);
+            const float4 c0 = ld4<LDS>(a, mo + 64), c1 = ld4<LDS>(a, mo + 80), c2 = ld4<LDS>(a, mo + 96),
+                         c3 = ld4<LDS>(a, mo + 112);
             f3 lhp = lo + ld * b.t;
-            f3 whp = mat_xyz(m->m2w, lhp, 1.0f);
+            f3 whp = mat_cols_xyz(c0, c1, c2, c3, lhp, 1.0f);
             f3 dv = ro - whp;
             float wdst = rtm::sqrt_(dot3(dv, dv));
             if (wdst < closest) {
@@ -302,27 +385,34 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
     Hit h;
     h.hit = any;
     h.dst = closest;
-    h.object = object;
+    h.mat_off = 0;
     h.point = f3{0, 0, 0};
     h.normal = f3{0, 0, 0};
     h.u = h.v = 0.0f;
     h.backface = false;
     if (any) {
+        DIAG(11);
         if (object >= 0) {
-            const DMesh* __restrict__ m = a.meshes + object;
-            const float4* __restrict__ sh = a.tri_shade + ((size_t)m->tri_offset + win.tri) * 4;
-            float4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3];
+            const uint32_t mo = a.lay.mesh_off + (uint32_t)object * MESH_REC_BYTES;
+            const uint32_t tri_base = fbits(ld4<LDS>(a, mo + 128).w);
+            const uint32_t so = a.lay.shade_off + (tri_base + win.tri) * TRI_SHADE_BYTES;
+            const float4 s0 = ld4<LDS>(a, so), s1 = ld4<LDS>(a, so + 16), s2 = ld4<LDS>(a, so + 32),
+                         s3 = ld4<LDS>(a, so + 48);
             f3 n1{s0.x, s0.y, s0.z}, n2{s1.x, s1.y, s1.z}, n3{s2.x, s2.y, s2.z};
             f3 ln = normalize3((n1 * win.w + n2 * win.u) + n3 * win.v) * sign_(win.det);
-            h.normal = normalize3(mat_xyz(m->m2w, ln, 0.0f));
+            const float4 c0 = ld4<LDS>(a, mo + 64), c1 = ld4<LDS>(a, mo + 80), c2 = ld4<LDS>(a, mo + 96),
+                         c3 = ld4<LDS>(a, mo + 112);
+            h.normal = normalize3(mat_cols_xyz(c0, c1, c2, c3, ln, 0.0f));
             h.backface = win.det < 0.0f;
             h.point = win_point;
             // uv = (uv1 * w + uv2 * u) + uv3 * v, uv1 = (u10,u11), uv2 = (u20,u21), uv3 = (u30,u31)
             h.u = (s0.w * win.w + s2.w * win.u) + s3.y * win.v;
             h.v = (s1.w * win.w + s3.x * win.u) + s3.z * win.v;
+            h.mat_off = a.lay.mat_off + (uint32_t)object * MATERIAL_BYTES;
         } else {
-            const DSphere sp = a.spheres[-object - 1];
-            f3 c{sp.cx, sp.cy, sp.cz};
+            const uint32_t si = (uint32_t)(-object - 1);
+            const float4 sp = ld4<LDS>(a, a.lay.sphere_off + si * SPHERE_BYTES);
+            f3 c{sp.x, sp.y, sp.z};
             h.point = ro + rd * s_dst;
             f3 n = normalize3(h.point - c);
             h.normal = s_inside ? -n : n;
@@ -332,10 +422,17 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             float phi = rtm::atan2_(-h.normal.z, -h.normal.x) + pi;
             h.u = phi / (2.0f * pi);
             h.v = theta / pi;
+            h.mat_off = a.lay.mat_off + (a.n_meshes + si) * MATERIAL_BYTES;
         }
     }
     return h;
 }
+
+// field byte offsets inside rt_material
+enum : uint32_t {
+    M_COLOR = 0, M_EMISSION = 16, M_SPECCOL = 32, M_ABSORB = 48, M_ABSORB_S = 64, M_EMISSION_S = 68,
+    M_SMOOTH = 72, M_SPECULAR = 76, M_IOR = 80, M_FLAG = 84, M_DIFFUSE_IDX = 88, M_NORMAL_IDX = 92
+};
 
 DEV f4 sample_texture(const RenderArgs& a, int index, float u, float v) {
     float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -367,36 +464,34 @@ DEV float reflectance(float cos_theta, float ior) {
 }
 
 // Blocks are dealt round-robin over the 8 XCDs (block b -> XCD b % 8).  Give
-// each XCD a contiguous run of tiles: bijection for any grid size.
-DEV uint32_t xcd_tile(uint32_t b, uint32_t nb) {
+// each XCD a contiguous run of work: bijection for any grid size.
+DEV uint32_t xcd_remap(uint32_t b, uint32_t nb) {
     uint32_t q = nb >> 3, r = nb & 7u;
     uint32_t x = b & 7u;
     uint32_t start = x * q + (x < r ? x : r);
     return start + (b >> 3);
 }
 
+// Pixel w (0..63) of local 8x8 tile `tile`: frame coordinates and output row.
 struct PixelCoord {
     uint32_t x, y, out_row;
     bool valid;
 };
 
-DEV PixelCoord pixel_of_lane(const RenderArgs& a) {
-    uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
-    uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    uint32_t lane = threadIdx.x & 63u;
-    uint32_t lx = lane & 7u, ly = lane >> 3;
+DEV PixelCoord pixel_of(const RenderArgs& a, uint32_t tile, uint32_t w) {
+    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     PixelCoord p;
-    p.x = tx * 8u + lx;
-    uint32_t strip = ty * a.strip_world + a.strip_rank;  // global 8-row strip
-    p.y = strip * 8u + ly;
-    p.out_row = a.strip_world > 1u ? ty * 8u + ly : p.y;
+    p.x = tx * 8u + (w & 7u);
+    const uint32_t strip = ty * a.strip_world + a.strip_rank;  // global 8-row strip
+    p.y = strip * 8u + (w >> 3);
+    p.out_row = a.strip_world > 1u ? ty * 8u + (w >> 3) : p.y;
     p.valid = p.x < a.params.width && p.y < a.params.height;
     return p;
 }
 
 // wgsl:154-161
-DEV void store_texel(const RenderArgs& a, const PixelCoord& p, f4 cur) {
-    float4* texel = a.image + (size_t)p.out_row * a.params.width + p.x;
+DEV void store_texel(const RenderArgs& a, uint32_t x, uint32_t out_row, f4 cur) {
+    float4* texel = a.image + (size_t)out_row * a.params.width + x;
     if (a.params.frames >= 1) {
         float4 prev = *texel;
         float weight = 1.0f / (float)(a.params.frames + 1);
@@ -408,137 +503,196 @@ DEV void store_texel(const RenderArgs& a, const PixelCoord& p, f4 cur) {
     }
 }
 
+// Stage the scene blob into LDS (coalesced 16-byte loads, whole workgroup) and
+// return this wave's stack column base.
+template <bool LDS>
+DEV uint32_t* block_prologue(const RenderArgs& a) {
+    uint32_t stack_base = 0;  // in float4 units
+    if constexpr (LDS) {
+        const uint32_t n16 = a.lay.bytes >> 4;
+        for (uint32_t i = threadIdx.x; i < n16; i += BLOCK_THREADS) lds_mem[i] = a.blob[i];
+        __syncthreads();
+        stack_base = n16;
+    }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t per_wave = (a.stack_entries ? a.stack_entries : 1u) * 128u;  // dwords
+    return reinterpret_cast<uint32_t*>(lds_mem + stack_base) + wave * per_wave + lane;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
 // wgsl `main` + `frag` + `trace` (wgsl:144-162, 473-500, 398-471)
 // ---------------------------------------------------------------------------
-template <bool STATS>
-__global__ void __launch_bounds__(64) rt_render_kernel(const RenderArgs a) {
-    extern __shared__ uint32_t lds_stack[];
-    uint32_t* stack = lds_stack + (threadIdx.x & 63u);
+namespace {
 
-    const PixelCoord px = pixel_of_lane(a);
-    const float sx = (float)a.params.width, sy = (float)a.params.height;
-    const float fx = (float)px.x, fy = (float)px.y;
+struct CameraConsts {  // wave-uniform
+    f3 origin, right, up;
+    float sx, sy;
+};
+
+DEV CameraConsts camera_consts(const RenderArgs& a) {
+    const float* __restrict__ c2w = &a.camera.cam_to_world[0][0];
+    CameraConsts c;
+    c.origin = f3{c2w[12], c2w[13], c2w[14]};
+    c.right = f3{c2w[0], c2w[1], c2w[2]};
+    c.up = f3{c2w[4], c2w[5], c2w[6]};
+    c.sx = (float)a.params.width;
+    c.sy = (float)a.params.height;
+    return c;
+}
+
+struct PixelState {
+    uint32_t x, out_row;   // where the texel goes
+    f3 focus;              // wgsl:482
+    uint32_t rng;          // wgsl:475, one stream per pixel
+    f4 total;              // wgsl:486
+    int32_t j;             // sample index (wgsl:487)
+    // current path (wgsl:398-471)
+    f3 ro, rd;
+    f4 T, light;
+    int32_t seg;
+    bool fresh;
+};
+
+// wgsl:475-484 for pixel (x, y) of the full frame
+DEV void pixel_begin(const RenderArgs& a, const CameraConsts& c, PixelState& s, uint32_t x, uint32_t y,
+                     uint32_t out_row) {
+    const float fx = (float)x, fy = (float)y;
     const int32_t fr = a.params.frames;
     const uint32_t absf = fr < 0 ? 0u - (uint32_t)fr : (uint32_t)fr;
-    uint32_t rng = (uint32_t)(fy * sx + fx) + absf * 719393u;  // wgsl:475
-
-    const float* __restrict__ c2w = &a.camera.cam_to_world[0][0];
-    const f3 cam_origin{c2w[12], c2w[13], c2w[14]};
-    const f3 cam_right{c2w[0], c2w[1], c2w[2]};
-    const f3 cam_up{c2w[4], c2w[5], c2w[6]};
-    const float uvx = fx / (sx - 1.0f), uvy = fy / (sy - 1.0f);
+    s.rng = (uint32_t)(fy * c.sx + fx) + absf * 719393u;
+    const float uvx = fx / (c.sx - 1.0f), uvy = fy / (c.sy - 1.0f);
     const f3 local_focus = f3{uvx - 0.5f, uvy - 0.5f, 1.0f} *
                            f3{a.camera.view_params[0], a.camera.view_params[1], a.camera.view_params[2]};
-    const f3 focus_point = mat_xyz(c2w, local_focus, 1.0f);
+    s.focus = mat_xyz(&a.camera.cam_to_world[0][0], local_focus, 1.0f);
+    s.x = x;
+    s.out_row = out_row;
+    s.total = f4{0, 0, 0, 0};
+    s.j = 0;
+    s.fresh = true;
+    s.seg = 0;
+    s.T = f4{1, 1, 1, 1};
+    s.light = f4{0, 0, 0, 0};
+    s.ro = f3{0, 0, 0};
+    s.rd = f3{0, 0, 1};
+}
 
-    const int32_t spp = a.params.rays_per_pixel;
+// One iteration of the per-lane state machine: (start the next sample) + one
+// path segment + its shading.  Returns true when the pixel's last sample ended.
+template <bool LDS, bool STATS>
+DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, uint32_t* stack,
+                   unsigned long long& n_segments, int& node_tests, int& tri_tests) {
     const int32_t nb = a.params.number_of_bounces;
-
-    f4 total{0, 0, 0, 0};
-    f4 light{0, 0, 0, 0}, T{1, 1, 1, 1};
-    f3 ro{0, 0, 0}, rd{0, 0, 1};
-    int32_t j = 0, seg = 0;
-    bool fresh = true;
-    bool active = px.valid && spp > 0;
-    unsigned long long n_segments = 0;
-    int node_tests = 0, tri_tests = 0;
-
-    while (active) {
-        if (fresh) {  // wgsl:487-495: next sample of this pixel
-            float jx, jy;
-            rand_in_unit_disk(rng, jx, jy);
-            jx = jx * a.camera.defocus_strength / sx;
-            jy = jy * a.camera.defocus_strength / sx;
-            ro = (cam_origin + cam_right * jx) + cam_up * jy;
-            float kx, ky;
-            rand_in_unit_disk(rng, kx, ky);
-            kx = kx * a.camera.diverge_strength / sx;
-            ky = ky * a.camera.diverge_strength / sx;
-            f3 jfp = (focus_point + cam_right * kx) + cam_up * ky;
-            rd = normalize3(jfp - ro);
-            rd = normalize3(rd);  // wgsl:400
-            T = f4{1, 1, 1, 1};
-            light = f4{0, 0, 0, 0};
-            seg = 0;
-            fresh = false;
-        }
-        bool end_path = true;
-        if (seg <= nb) {
-            Hit hit = intersect_scene<STATS>(a, ro, rd, stack, node_tests, tri_tests);
-            n_segments += 1;
-            if (!hit.hit) {
-                if (a.params.skybox != 0) light = light + T * environment_light(rd);
-            } else {
-                const rt_material* __restrict__ mat =
-                    hit.object >= 0 ? a.mesh_materials + hit.object : a.sphere_materials + (-hit.object - 1);
-                const int flag = mat->flag;
-                ro = hit.point;
-                if (flag == RT_MATERIAL_GLASS) {  // wgsl:414-436
-                    if (hit.backface) {
-                        float as = mat->absorption_strength;
-                        float ex = ((-hit.dst) * mat->absorption[0]) * as;
-                        float ey = ((-hit.dst) * mat->absorption[1]) * as;
-                        float ez = ((-hit.dst) * mat->absorption[2]) * as;
-                        T = f4{T.x * rtm::exp_(ex), T.y * rtm::exp_(ey), T.z * rtm::exp_(ez), 1.0f};
-                    }
-                    float mior = mat->ior;
-                    float ior = hit.backface ? mior : (1.0f / mior);
-                    f3 reflect_dir = reflect3(rd, hit.normal);
-                    f3 refract_dir = refract3(rd, hit.normal, ior);
-                    float cos_theta = min_(dot3(-rd, hit.normal), 1.0f);
-                    float sin_theta = rtm::sqrt_(1.0f - cos_theta * cos_theta);
-                    bool cannot_refract = ior * sin_theta > 1.0f;
-                    bool follow_reflection = cannot_refract;
-                    if (!cannot_refract) follow_reflection = reflectance(cos_theta, ior) > rand_(rng);
-                    f3 diffuse_dir = normalize3(hit.normal + rand_unit_sphere(rng));
-                    reflect_dir = normalize3(mix3(diffuse_dir, reflect_dir, mat->specular));
-                    refract_dir = normalize3(mix3(-diffuse_dir, refract_dir, mat->smoothness));
-                    rd = follow_reflection ? reflect_dir : refract_dir;
-                    ro = hit.point + (1e-4f * hit.normal) * sign_(dot3(hit.normal, rd));
-                } else {  // wgsl:437-460
-                    bool is_spec = mat->specular >= rand_(rng);
-                    f3 sph = rand_unit_sphere(rng);
-                    f3 diffuse_dir = sph * sign_(dot3(hit.normal, sph));
-                    f3 specular_dir = reflect3(rd, hit.normal);
-                    float es = mat->emission_strength;
-                    f4 emitted{mat->emission_color[0] * es, mat->emission_color[1] * es,
-                               mat->emission_color[2] * es, mat->emission_color[3] * es};
-                    rd = normalize3(mix3(diffuse_dir, specular_dir, mat->smoothness * (is_spec ? 1.0f : 0.0f)));
-                    light = light + emitted * T;
-                    f4 color;
-                    if (flag == RT_MATERIAL_TEXTURE && mat->diffuse_index != -1) {
-                        color = sample_texture(a, mat->diffuse_index, hit.u, hit.v);
-                    } else {
-                        color = f4{mat->color[0], mat->color[1], mat->color[2], mat->color[3]};
-                    }
-                    f4 spec{mat->specular_color[0], mat->specular_color[1], mat->specular_color[2],
-                            mat->specular_color[3]};
-                    T = T * (is_spec ? spec : color);
+    DIAG(0);
+    if (s.fresh) {  // wgsl:487-495: next sample of this pixel
+        DIAG(1);
+        float jx, jy;
+        rand_in_unit_disk(s.rng, jx, jy);
+        jx = jx * a.camera.defocus_strength / c.sx;
+        jy = jy * a.camera.defocus_strength / c.sx;
+        s.ro = (c.origin + c.right * jx) + c.up * jy;
+        float kx, ky;
+        rand_in_unit_disk(s.rng, kx, ky);
+        kx = kx * a.camera.diverge_strength / c.sx;
+        ky = ky * a.camera.diverge_strength / c.sx;
+        f3 jfp = (s.focus + c.right * kx) + c.up * ky;
+        s.rd = normalize3(jfp - s.ro);
+        s.rd = normalize3(s.rd);  // wgsl:400
+        s.T = f4{1, 1, 1, 1};
+        s.light = f4{0, 0, 0, 0};
+        s.seg = 0;
+        s.fresh = false;
+    }
+    bool end_path = true;
+    if (s.seg <= nb) {
+        Hit hit = intersect_scene<LDS, STATS>(a, s.ro, s.rd, stack, node_tests, tri_tests);
+        n_segments += 1;
+        if (!hit.hit) {
+            DIAG(12);
+            if (a.params.skybox != 0) s.light = s.light + s.T * environment_light(s.rd);
+        } else {
+            const uint32_t mo = hit.mat_off;
+            const int flag = ldi<LDS>(a, mo + M_FLAG);
+            f3 rd = s.rd;
+            f4 T = s.T;
+            s.ro = hit.point;
+            if (flag == RT_MATERIAL_GLASS) {  // wgsl:414-436
+                DIAG(14);
+                if (hit.backface) {
+                    const float4 ab = ld4<LDS>(a, mo + M_ABSORB);
+                    float as = ldf<LDS>(a, mo + M_ABSORB_S);
+                    float ex = ((-hit.dst) * ab.x) * as;
+                    float ey = ((-hit.dst) * ab.y) * as;
+                    float ez = ((-hit.dst) * ab.z) * as;
+                    T = f4{T.x * rtm::exp_(ex), T.y * rtm::exp_(ey), T.z * rtm::exp_(ez), 1.0f};
                 }
-                float p = max_(T.x, max_(T.y, T.z));  // wgsl:462-466
-                bool die = rand_(rng) >= p;
-                if (!die) {
-                    T = T * (1.0f / p);
-                    seg += 1;
-                    end_path = seg > nb;
+                float mior = ldf<LDS>(a, mo + M_IOR);
+                float ior = hit.backface ? mior : (1.0f / mior);
+                f3 reflect_dir = reflect3(rd, hit.normal);
+                f3 refract_dir = refract3(rd, hit.normal, ior);
+                float cos_theta = min_(dot3(-rd, hit.normal), 1.0f);
+                float sin_theta = rtm::sqrt_(1.0f - cos_theta * cos_theta);
+                bool cannot_refract = ior * sin_theta > 1.0f;
+                bool follow_reflection = cannot_refract;
+                if (!cannot_refract) follow_reflection = reflectance(cos_theta, ior) > rand_(s.rng);
+                f3 diffuse_dir = normalize3(hit.normal + rand_unit_sphere(s.rng));
+                reflect_dir = normalize3(mix3(diffuse_dir, reflect_dir, ldf<LDS>(a, mo + M_SPECULAR)));
+                refract_dir = normalize3(mix3(-diffuse_dir, refract_dir, ldf<LDS>(a, mo + M_SMOOTH)));
+                rd = follow_reflection ? reflect_dir : refract_dir;
+                s.ro = hit.point + (1e-4f * hit.normal) * sign_(dot3(hit.normal, rd));
+            } else {  // wgsl:437-460
+                DIAG(13);
+                const float4 msc = ld4<LDS>(a, mo + M_ABSORB_S);  // (absorb_s, emission_s, smoothness, specular)
+                bool is_spec = msc.w >= rand_(s.rng);
+                f3 sph = rand_unit_sphere(s.rng);
+                f3 diffuse_dir = sph * sign_(dot3(hit.normal, sph));
+                f3 specular_dir = reflect3(rd, hit.normal);
+                const float4 ec = ld4<LDS>(a, mo + M_EMISSION);
+                float es = msc.y;
+                f4 emitted{ec.x * es, ec.y * es, ec.z * es, ec.w * es};
+                rd = normalize3(mix3(diffuse_dir, specular_dir, msc.z * (is_spec ? 1.0f : 0.0f)));
+                s.light = s.light + emitted * T;
+                f4 color;
+                const int diffuse_index = ldi<LDS>(a, mo + M_DIFFUSE_IDX);
+                if (flag == RT_MATERIAL_TEXTURE && diffuse_index != -1) {
+                    color = sample_texture(a, diffuse_index, hit.u, hit.v);
+                } else {
+                    const float4 cc = ld4<LDS>(a, mo + M_COLOR);
+                    color = f4{cc.x, cc.y, cc.z, cc.w};
                 }
+                const float4 sc = ld4<LDS>(a, mo + M_SPECCOL);
+                f4 spec{sc.x, sc.y, sc.z, sc.w};
+                T = T * (is_spec ? spec : color);
             }
-        }
-        if (end_path) {  // wgsl:496
-            total = total + light;
-            j += 1;
-            fresh = true;
-            active = j < spp;
+            s.rd = rd;
+            float p = max_(T.x, max_(T.y, T.z));  // wgsl:462-466
+            bool die = rand_(s.rng) >= p;
+            if (!die) {
+                T = T * (1.0f / p);
+                s.seg += 1;
+                end_path = s.seg > nb;
+            }
+            s.T = T;
         }
     }
+    if (end_path) {  // wgsl:496
+        s.total = s.total + s.light;
+        s.j += 1;
+        s.fresh = true;
+        return s.j >= a.params.rays_per_pixel;
+    }
+    return false;
+}
 
-    if (px.valid) {
-        float n = (float)spp;
-        store_texel(a, px, f4{total.x / n, total.y / n, total.z / n, total.w / n});
-    }
+// wgsl:498 + 154-161
+DEV void pixel_finish(const RenderArgs& a, const PixelState& s) {
+    float n = (float)a.params.rays_per_pixel;
+    store_texel(a, s.x, s.out_row, f4{s.total.x / n, s.total.y / n, s.total.z / n, s.total.w / n});
+}
+
+template <bool STATS>
+DEV void flush_counters(const RenderArgs& a, unsigned long long n_segments, int node_tests, int tri_tests) {
     if (a.counters) {
         atomicAdd(&a.counters->segments, n_segments);
         if (STATS) {
@@ -548,13 +702,112 @@ __global__ void __launch_bounds__(64) rt_render_kernel(const RenderArgs a) {
     }
 }
 
+}  // namespace
+
+// Variant 1: one wave per 8x8 tile (the reference's dispatch shape), four
+// tiles per workgroup.
+template <bool LDS, bool STATS>
+__global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_kernel(const RenderArgs a) {
+    uint32_t* stack = block_prologue<LDS>(a);
+    const CameraConsts cam = camera_consts(a);
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x) * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const bool tile_ok = tile < a.tiles_x * a.tiles_y;
+    const PixelCoord px = pixel_of(a, tile_ok ? tile : 0u, threadIdx.x & 63u);
+    const bool valid = tile_ok && px.valid;
+    PixelState s;
+    pixel_begin(a, cam, s, px.x, px.y, px.out_row);
+    bool active = valid && a.params.rays_per_pixel > 0;
+    unsigned long long n_segments = 0;
+    int node_tests = 0, tri_tests = 0;
+    while (active) {
+        if (path_step<LDS, STATS>(a, cam, s, stack, n_segments, node_tests, tri_tests)) active = false;
+    }
+    if (valid) pixel_finish(a, s);
+    flush_counters<STATS>(a, n_segments, node_tests, tri_tests);
+}
+
+// Variant 0 (default): persistent waves with active-lane refill.  Each wave
+// pulls 8x8 tiles from a global counter; whenever lanes have finished their
+// pixel, a ballot + prefix count (mbcnt) hands them the next pixels of the
+// wave's current tile, so the wave stays full until the frame runs out.  The
+// per-pixel RNG stream depends only on the pixel's coordinates, so the image
+// does not depend on which lane rendered which pixel.
+template <bool LDS, bool STATS>
+__global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persistent_kernel(const RenderArgs a) {
+    uint32_t* stack = block_prologue<LDS>(a);
+    const uint32_t lane = threadIdx.x & 63u;
+    const CameraConsts cam = camera_consts(a);
+    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
+    const bool have_samples = a.params.rays_per_pixel > 0;
+
+    uint32_t pool_base = 0, pool_left = 0;  // wave-uniform: pixels left in the current tile
+    bool exhausted = false;
+    PixelState s;
+    pixel_begin(a, cam, s, 0, 0, 0);
+    bool active = false;
+    unsigned long long n_segments = 0;
+    int node_tests = 0, tri_tests = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (idle != 0ull && !exhausted) {
+            if (pool_left == 0) {
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(a.work_counter, 1u);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t >= n_tiles) {
+                    exhausted = true;
+                } else {
+                    pool_base = t * 64u;
+                    pool_left = 64u;
+                }
+            }
+            if (pool_left != 0) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (!active && rank < pool_left) {
+                    const uint32_t q = pool_base + rank;
+                    const PixelCoord px = pixel_of(a, q >> 6, q & 63u);
+                    if (px.valid) {
+                        DIAG(15);
+                        pixel_begin(a, cam, s, px.x, px.y, px.out_row);
+                        if (have_samples) {
+                            active = true;
+                        } else {
+                            pixel_finish(a, s);  // 0 / 0 = NaN, as the shader would store
+                        }
+                    }
+                }
+                const uint32_t n_idle = (uint32_t)__popcll(idle);
+                const uint32_t n = n_idle < pool_left ? n_idle : pool_left;
+                pool_base += n;
+                pool_left -= n;
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (active) {
+            if (path_step<LDS, STATS>(a, cam, s, stack, n_segments, node_tests, tri_tests)) {
+                DIAG(16);
+                pixel_finish(a, s);
+                active = false;
+            }
+        }
+    }
+    flush_counters<STATS>(a, n_segments, node_tests, tri_tests);
+}
+
 // ---------------------------------------------------------------------------
 // wgsl debug_trace (wgsl:502-573): one primary ray, no RNG.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) rt_debug_kernel(const RenderArgs a) {
-    extern __shared__ uint32_t lds_stack[];
-    uint32_t* stack = lds_stack + (threadIdx.x & 63u);
-    const PixelCoord px = pixel_of_lane(a);
+template <bool LDS>
+__global__ void __launch_bounds__(BLOCK_THREADS) rt_debug_kernel(const RenderArgs a) {
+    uint32_t* stack = block_prologue<LDS>(a);
+    const uint32_t tile = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (tile >= a.tiles_x * a.tiles_y) return;
+    const PixelCoord px = pixel_of(a, tile, threadIdx.x & 63u);
     if (!px.valid) return;
     const float sx = (float)a.params.width, sy = (float)a.params.height;
     const float fx = (float)px.x, fy = (float)px.y;
@@ -566,7 +819,7 @@ __global__ void __launch_bounds__(64) rt_debug_kernel(const RenderArgs a) {
     const f3 focus_point = mat_xyz(c2w, local_focus, 1.0f);
     f3 rd = normalize3(focus_point - cam_origin);
     int s0 = 0, s1 = 0;
-    Hit hit = intersect_scene<true>(a, cam_origin, rd, stack, s0, s1);
+    Hit hit = intersect_scene<LDS, true>(a, cam_origin, rd, stack, s0, s1);
     const float scale = (float)a.params.debug_scale;
     f4 out{1.0f, 0.0f, 1.0f, 1.0f};
     switch (a.params.debug_flag) {
@@ -589,10 +842,10 @@ __global__ void __launch_bounds__(64) rt_debug_kernel(const RenderArgs a) {
             if (!hit.hit) {
                 out = f4{0, 0, 0, 0};
             } else {
-                const rt_material* mat =
-                    hit.object >= 0 ? a.mesh_materials + hit.object : a.sphere_materials + (-hit.object - 1);
-                if (mat->flag == RT_MATERIAL_TEXTURE && mat->normal_index != -1) {
-                    f4 x = sample_texture(a, mat->normal_index, hit.u, hit.v);
+                const int flag = ldi<LDS>(a, hit.mat_off + M_FLAG);
+                const int normal_index = ldi<LDS>(a, hit.mat_off + M_NORMAL_IDX);
+                if (flag == RT_MATERIAL_TEXTURE && normal_index != -1) {
+                    f4 x = sample_texture(a, normal_index, hit.u, hit.v);
                     out = f4{0.5f * (2.0f * x.x - 1.0f) + 0.5f, 0.5f * (2.0f * x.y - 1.0f) + 0.5f,
                              0.5f * (2.0f * x.z - 1.0f) + 0.5f, 1.0f};
                 } else {
@@ -622,7 +875,7 @@ __global__ void __launch_bounds__(64) rt_debug_kernel(const RenderArgs a) {
         }
         default: break;
     }
-    store_texel(a, px, out);
+    store_texel(a, px.x, px.out_row, out);
     if (a.counters) {
         atomicAdd(&a.counters->segments, 1ull);
         atomicAdd(&a.counters->node_tests, (unsigned long long)s0);
@@ -645,18 +898,50 @@ __global__ void rt_assemble_kernel(const float4* __restrict__ gathered, float4* 
     image[i] = gathered[(unsigned long long)rank * pad_texels + (unsigned long long)(ls * 8u + ly) * width + x];
 }
 
-// Launchers (called from rt_api.hip)
-hipError_t launch_render(const RenderArgs& a, hipStream_t stream) {
-    uint32_t nblocks = a.tiles_x * a.tiles_y;
-    if (nblocks == 0) return hipSuccess;
-    size_t lds = (size_t)(a.stack_entries ? a.stack_entries : 1u) * 64u * sizeof(uint32_t);
-    if (a.params.debug_flag != 0) {
-        hipLaunchKernelGGL(rt_debug_kernel, dim3(nblocks), dim3(64), lds, stream, a);
-    } else if (a.count_tests) {
-        hipLaunchKernelGGL(rt_render_kernel<true>, dim3(nblocks), dim3(64), lds, stream, a);
-    } else {
-        hipLaunchKernelGGL(rt_render_kernel<false>, dim3(nblocks), dim3(64), lds, stream, a);
+#if defined(RT_DIAG)
+hipError_t diag_read(unsigned long long* out, bool reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 64);
+    if (e != hipSuccess) return e;
+    if (reset) {
+        unsigned long long z[64] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof(z));
     }
+    return e;
+}
+#endif
+
+// Launchers (called from rt_api.hip)
+size_t render_lds_bytes(const RenderArgs& a) {
+    size_t stacks = (size_t)(a.stack_entries ? a.stack_entries : 1u) * 128u * sizeof(uint32_t) * WAVES_PER_BLOCK;
+    return stacks + (a.lds_scene ? a.lay.bytes : 0u);
+}
+
+template <bool LDS>
+static void launch_variant(const RenderArgs& a, uint32_t ntiles, size_t lds, hipStream_t stream) {
+    const uint32_t tile_blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (a.params.debug_flag != 0) {
+        hipLaunchKernelGGL(rt_debug_kernel<LDS>, dim3(tile_blocks), dim3(BLOCK_THREADS), lds, stream, a);
+    } else if (a.kernel_variant == 1) {
+        if (a.count_tests)
+            hipLaunchKernelGGL((rt_render_tiles_kernel<LDS, true>), dim3(tile_blocks), dim3(BLOCK_THREADS), lds, stream, a);
+        else
+            hipLaunchKernelGGL((rt_render_tiles_kernel<LDS, false>), dim3(tile_blocks), dim3(BLOCK_THREADS), lds, stream, a);
+    } else {
+        uint32_t blocks = a.persistent_blocks < tile_blocks ? a.persistent_blocks : tile_blocks;
+        if (blocks == 0) blocks = 1;
+        if (a.count_tests)
+            hipLaunchKernelGGL((rt_render_persistent_kernel<LDS, true>), dim3(blocks), dim3(BLOCK_THREADS), lds, stream, a);
+        else
+            hipLaunchKernelGGL((rt_render_persistent_kernel<LDS, false>), dim3(blocks), dim3(BLOCK_THREADS), lds, stream, a);
+    }
+}
+
+hipError_t launch_render(const RenderArgs& a, hipStream_t stream) {
+    uint32_t ntiles = a.tiles_x * a.tiles_y;
+    if (ntiles == 0) return hipSuccess;
+    size_t lds = render_lds_bytes(a);
+    if (a.lds_scene) launch_variant<true>(a, ntiles, lds, stream);
+    else launch_variant<false>(a, ntiles, lds, stream);
     return hipGetLastError();
 }
 

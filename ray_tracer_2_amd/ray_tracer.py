@@ -96,6 +96,9 @@ class RayTracer:
     def set_counters(self, enabled):
         self._check(self._L.rt_set_counters(self._h, int(enabled)))
 
+    def set_option(self, name, value):
+        self._check(self._L.rt_set_option(self._h, name.encode(), int(value)))
+
     def reset_timing(self):
         self._check(self._L.rt_reset_timing(self._h))
 

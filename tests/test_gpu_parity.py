@@ -23,10 +23,16 @@ def assert_bit_equal(gpu, ref, what):
                              f"max rel err {np.nanmax(rel):.3e}")
 
 
-@pytest.fixture(scope="module")
-def loaded(tracer, cornell):
+@pytest.fixture(scope="module", params=[(0, 1), (1, 1), (0, 0), (1, 0)],
+                ids=["persistent-lds", "tiles-lds", "persistent-global", "tiles-global"])
+def loaded(request, tracer, cornell):
+    """Every kernel variant x scene placement must produce the same bits."""
     tracer.load_scene(cornell)
-    return tracer
+    tracer.set_option("kernel_variant", request.param[0])
+    tracer.set_option("lds_scene", request.param[1])
+    yield tracer
+    tracer.set_option("kernel_variant", 0)
+    tracer.set_option("lds_scene", 1)
 
 
 @pytest.mark.parametrize("mode", range(1, 8))

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Divergence census (diagnostic build, -DRT_DIAG=1): for each code section,
+how many times a wave entered it and how many lanes were active on average.
+    python tools/diag.py [variant]
+Builds ray_tracer_2_amd/librt2_mi355x_diag.so on first use (hipcc).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ray_tracer_2_amd import build  # noqa: E402
+
+DIAG_SO = os.path.join(ROOT, "ray_tracer_2_amd", "librt2_mi355x_diag.so")
+SECTIONS = {0: "iteration (path_step)", 1: "sample start (ray gen)", 3: "mesh transform",
+            4: "root-leaf tri: det", 5: "root-leaf tri: body", 6: "bvh: node visit", 7: "bvh: internal (2 aabb)",
+            8: "bvh-leaf tri: det", 9: "bvh-leaf tri: body", 10: "mesh hit -> world", 11: "winner finalize",
+            12: "miss: sky", 13: "shade: diffuse", 14: "shade: glass", 15: "refill: pixel_begin",
+            16: "pixel_finish"}
+
+
+def build_diag():
+    srcs = [os.path.join(build.CSRC, s) for s in build.PRODUCT_SOURCES]
+    if os.path.exists(DIAG_SO) and all(os.path.getmtime(DIAG_SO) > os.path.getmtime(s) for s in srcs):
+        return
+    subprocess.run([build.hipcc_path(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
+                    "-fno-fast-math", "-fPIC", "-shared", "-DRT_DIAG=1", "-I", os.path.join(ROOT, "include"),
+                    *srcs, "-lz", "-o", DIAG_SO], check=True)
+
+
+def main():
+    build_diag()
+    if "--build-only" in sys.argv:
+        return
+    import ray_tracer_2_amd.lib as lib
+    lib.LIB_PATH = DIAG_SO
+    import ray_tracer_2_amd as rt
+    variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    W, H = 960, 540
+    arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
+    tr = rt.RayTracer(0, W, H)
+    tr.load_scene(arrays)
+    tr.set_option("kernel_variant", variant)
+    L = rt.load()
+    buf = (C.c_uint64 * 64)()
+    L.rt_diag_read(tr._h, buf, 1)
+    tr.render(rt.make_params(W, H, 4, 8, skybox=1, frames=0))
+    L.rt_diag_read(tr._h, buf, 1)
+    it = buf[0]
+    print(f"variant {variant}: {W}x{H}, 8 spp, 4 bounces")
+    print(f"{'section':28s} {'wave visits':>12s} {'per iter':>9s} {'avg lanes':>9s} {'util':>6s}")
+    for k, name in SECTIONS.items():
+        v, l = buf[2 * k], buf[2 * k + 1]
+        if v:
+            print(f"{name:28s} {v:12d} {v / it:9.2f} {l / v:9.1f} {l / v / 64:6.1%}")
+
+
+if __name__ == "__main__":
+    main()
