@@ -1,0 +1,227 @@
+"""GPU parity beyond the Cornell config: spheres, glass, specular, depth of
+field, textures, transformed meshes, multi-strip rendering, full-size
+properties, and the C ABI's error behaviour.  All image comparisons are
+bit-exact against the CPU oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bits
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(ROOT, "tests", "data")
+
+
+def same(gpu, ref):
+    return np.array_equal(bits(gpu), bits(ref))
+
+
+def render_both(rt, oracle, tracer, arrays, params):
+    tracer.load_scene(arrays)
+    tracer.reset_timing()
+    if params.frames >= 1:   # accumulation blends with the previous image: start both sides from zero
+        tracer.write_image(np.zeros((params.height, params.width, 4), np.float32))
+    tracer.render(params)
+    gpu = tracer.read_image(params.width, params.height)
+    ref, st = oracle.render(params, arrays)
+    return gpu, ref, tracer.stats(), st
+
+
+@pytest.mark.parametrize("name", ["room", "metal", "balls"])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_sphere_and_glass_scenes(rt, oracle, tracer, name, variant):
+    """scene.rs library scenes: spheres (ray_sphere), glass (refract, Beer-Lambert,
+    short-circuit Fresnel draw), specular bounces, quads with BVH leaves."""
+    arrays = rt.SceneArrays.from_scene(rt.Scene.from_name(name, DATA))
+    tracer.set_option("kernel_variant", variant)
+    try:
+        gpu, ref, s, st = render_both(rt, oracle, tracer, arrays, rt.make_params(160, 90, 5, 4, skybox=1, frames=2))
+    finally:
+        tracer.set_option("kernel_variant", 0)
+    assert same(gpu, ref)
+    assert s.segments == st.segments
+
+
+def test_depth_of_field_and_divergence(rt, oracle, tracer):
+    sc = rt.Scene.from_name("room", DATA)
+    sc.set_camera((0, 1, 3), (0, 1, 2), fov=45.0, focus_dist=2.5, defocus_strength=100.0, diverge_strength=1.5)
+    arrays = rt.SceneArrays.from_scene(sc)
+    gpu, ref, _, _ = render_both(rt, oracle, tracer, arrays, rt.make_params(128, 72, 3, 4, frames=0))
+    assert same(gpu, ref)
+
+
+def test_transformed_meshes_and_glass_mesh(rt, oracle, tracer):
+    """Non-identity world_to_model (rotation + non-uniform scale), different per mesh,
+    plus a glass mesh (no backface culling, wgsl:375)."""
+    sc = rt.Scene()
+    sc.set_camera((0, 1.0, 4.0), (0, 0.5, 0), fov=50.0)
+    h = float(np.sqrt(0.5))
+    quad = [[-1, 0, -1, 0, 1, 0, 0, 0], [1, 0, -1, 0, 1, 0, 1, 0], [1, 0, 1, 0, 1, 0, 1, 1], [-1, 0, 1, 0, 1, 0, 0, 1]]
+    sc.add_mesh_from_data(quad, [2, 1, 0, 3, 2, 0], xform=rt.transform(scale=(4, 1, 4)),
+                          mat=rt.material(color=(0.8, 0.8, 0.7, 1), smoothness=0.0))
+    sc.add_mesh_from_file("quirks.obj", assets_dir=DATA, use_mtl=True,
+                          xform=rt.transform(pos=(-1.0, 0.2, 0.0), rot=(0, h, 0, h), scale=(1.5, 1.0, 0.7)))
+    sc.add_mesh_from_file("quirks.obj", assets_dir=DATA, use_mtl=False,
+                          xform=rt.transform(pos=(0.5, 0.1, 0.5), rot=(0.2, 0, 0, 0.9797959), scale=(0.6, 0.6, 0.6)),
+                          mat=rt.material(color=(0.9, 0.9, 1, 1), flag=1, ior=1.45, smoothness=0.9, specular=0.8,
+                                          absorption=(0.2, 0.1, 0.05, 0), absorption_strength=1.5))
+    sc.add_sphere((1.5, 0.6, -0.5), 0.6, rt.material(color=(1, 1, 1, 1), emission_color=(1, 0.9, 0.8, 1), emission_strength=6.0))
+    sc.build()
+    arrays = rt.SceneArrays.from_scene(sc)
+    for dbg in (0, 1, 2, 3, 7):
+        p = rt.make_params(144, 80, 6, 3, skybox=1, frames=0, debug_flag=dbg, debug_scale=10)
+        gpu, ref, _, _ = render_both(rt, oracle, tracer, arrays, p)
+        assert same(gpu, ref), dbg
+
+
+def test_textured_materials(rt, oracle, tracer):
+    """textureSampleLevel: sRGB decode, bilinear, repeat (wgsl:454-455) on a mesh and a sphere."""
+    rng = np.random.RandomState(3)
+    tex = rng.randint(0, 256, (16, 8, 4), dtype=np.uint8)
+    tex2 = rng.randint(0, 256, (5, 3, 4), dtype=np.uint8)
+    sc = rt.Scene()
+    sc.set_camera((0, 0.8, 2.5), (0, 0.3, 0), fov=60.0)
+    i0 = sc.add_texture_rgba8(tex)
+    i1 = sc.add_texture_rgba8(tex2)
+    quad = [[-2, 0, -2, 0, 1, 0, -1.5, -0.5], [2, 0, -2, 0, 1, 0, 2.5, -0.5], [2, 0, 2, 0, 1, 0, 2.5, 3.5], [-2, 0, 2, 0, 1, 0, -1.5, 3.5]]
+    sc.add_mesh_from_data(quad, [2, 1, 0, 3, 2, 0], mat=rt.material(flag=2, diffuse_index=i0, smoothness=0.0))
+    sc.add_sphere((0, 0.6, 0), 0.6, rt.material(flag=2, diffuse_index=i1, normal_index=i0, smoothness=0.2, specular=0.1,
+                                                 specular_color=(1, 1, 1, 1)))
+    sc.add_sphere((1.2, 0.4, 0.3), 0.4, rt.material(flag=2, diffuse_index=40))   # index of a 1x1 zero dummy texture
+    sc.build()
+    arrays = rt.SceneArrays.from_scene(sc)
+    for dbg in (0, 1, 3):
+        p = rt.make_params(128, 72, 3, 4, skybox=1, frames=1, debug_flag=dbg, debug_scale=4)
+        tracer.write_image(np.zeros((72, 128, 4), np.float32))
+        gpu, ref, _, _ = render_both(rt, oracle, tracer, arrays, p)
+        assert same(gpu, ref), dbg
+    # the shared sampler itself, on and beyond the [0, 1) range
+    uv = rng.uniform(-2, 3, (64, 2)).astype(np.float32)
+    assert np.isfinite(oracle.sample_texture(tex, uv)).all()
+
+
+def test_edge_params(rt, oracle, tracer, cornell):
+    tracer.load_scene(cornell)
+    for kw in (dict(bounces=0, spp=1), dict(bounces=-1, spp=2), dict(bounces=3, spp=0), dict(bounces=2, spp=1, frames=-1),
+               dict(bounces=2, spp=1, frames=7, skybox=0)):
+        p = rt.make_params(40, 24, kw["bounces"], kw["spp"], skybox=kw.get("skybox", 1), frames=kw.get("frames", 0))
+        tracer.write_image(np.full((24, 40, 4), 0.25, np.float32))
+        tracer.render(p)
+        gpu = tracer.read_image(40, 24)
+        ref, _ = oracle.render(p, cornell, image=np.full((24, 40, 4), 0.25, np.float32))
+        assert np.array_equal(bits(gpu), bits(ref)), kw   # spp = 0 stores NaN (0/0) on both sides
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_strips_assemble_to_the_full_frame(rt, tracer, cornell, world):
+    """rt_render_strips + rt_assemble_strips on one GPU: the stitched frame equals rt_render's."""
+    w, h = 200, 100   # 13 strips, ragged last strip
+    p = rt.make_params(w, h, 4, 4, frames=0)
+    tracer.load_scene(cornell)
+    tracer.render(p)
+    full = tracer.read_image(w, h)
+    pad = tracer.strip_texels(w, h, 0, world)
+    gathered = np.zeros((world, pad, 4), np.float32)
+    small = rt.RayTracer(0, w, h)
+    small.load_scene(cornell)
+    for r in range(world):
+        small.render_strips(p, r, world)
+        n = small.strip_texels(w, h, r, world)
+        gathered[r, :n] = small.read_texels(n)
+    # upload the gathered buffer into the small tracer's own image memory and scatter into `tracer`
+    stage = rt.RayTracer(0, world * pad, 1)
+    stage.write_image(gathered.reshape(1, world * pad, 4))
+    tracer.assemble_strips(stage.device_image_ptr, w, h, world)
+    got = tracer.read_image(w, h)
+    assert np.array_equal(bits(got), bits(full))
+    small.close()
+    stage.close()
+
+
+def test_full_size_properties(rt, oracle, tracer, cornell):
+    """BASELINE config 2 at full size (1920x1080, 8 spp, 4 bounces): properties that do
+    not need the whole oracle frame."""
+    W, H = 1920, 1080
+    tracer.load_scene(cornell)
+    p0 = rt.make_params(W, H, 4, 8, frames=0)
+    tracer.reset_timing()
+    tracer.render(p0)
+    a = tracer.read_image(W, H)
+    rays0 = tracer.stats().segments
+    # (1) sampled rows against the oracle, bit for bit
+    rows = np.array([0, 1, 7, 8, 300, 539, 540, 541, 1000, 1079], np.uint32)
+    ref = np.zeros((H, W, 4), np.float32)
+    ref, _ = oracle.render(p0, cornell, image=ref, rows=rows)
+    assert np.array_equal(bits(a[rows]), bits(ref[rows]))
+    # (2) determinism and independence from the kernel variant / scene placement
+    for variant, lds in ((1, 1), (0, 0)):
+        tracer.set_option("kernel_variant", variant)
+        tracer.set_option("lds_scene", lds)
+        tracer.reset_timing()
+        tracer.render(p0)
+        assert np.array_equal(bits(tracer.read_image(W, H)), bits(a))
+        assert tracer.stats().segments == rays0
+    tracer.set_option("kernel_variant", 0)
+    tracer.set_option("lds_scene", 1)
+    # (3) accumulation: frame 1 stored = prev*(1-w) + cur*w with cur = the frames=-1 render (same seed)
+    tracer.render(rt.make_params(W, H, 4, 8, frames=1))
+    acc = tracer.read_image(W, H)
+    tracer.render(rt.make_params(W, H, 4, 8, frames=-1))
+    cur = tracer.read_image(W, H)
+    w = np.float32(0.5)
+    assert np.array_equal(bits(acc), bits(a * (np.float32(1) - w) + cur * w))
+    # (4) every path has between 1 and bounces + 1 segments
+    assert W * H * 8 <= rays0 <= W * H * 8 * 5
+    assert np.isfinite(a).all() and (a[..., :3] >= 0).all()
+
+
+def test_error_codes(rt, tracer, cornell):
+    L = rt.load()
+    t = rt.RayTracer(0, 64, 64)
+    with pytest.raises(rt.RtError) as e:
+        t.render(rt.make_params(32, 32, 1, 1))
+    assert e.value.code == -4   # RT_ERR_NO_SCENE
+    t.load_scene(cornell)
+    with pytest.raises(rt.RtError) as e:
+        t.render(rt.make_params(128, 128, 1, 1))
+    assert e.value.code == -2   # larger than the image given to rt_create
+    # capacity limits of the reference's fixed buffers (ray_tracer.rs:15-19)
+    u = cornell.uniform
+    bad = rt.SceneArrays(u, np.zeros(501, cornell.spheres.dtype), cornell.meshes, cornell.triangles, cornell.nodes)
+    bad.uniform = type(u).from_buffer_copy(bytes(u))
+    bad.uniform.spheres = 501
+    with pytest.raises(rt.RtError) as e:
+        t.update_buffers(bad)
+    assert e.value.code == -2
+    # corrupt BVH: child index out of range, and a cycle
+    nodes = cornell.nodes.copy()
+    nodes["left"][2] = 1000
+    with pytest.raises(rt.RtError) as e:
+        t.update_buffers(rt.SceneArrays(u, cornell.spheres, cornell.meshes, cornell.triangles, nodes))
+    assert e.value.code == -9
+    nodes = cornell.nodes.copy()
+    nodes["left"][2] = 0   # root of backWall points at itself
+    with pytest.raises(rt.RtError) as e:
+        t.update_buffers(rt.SceneArrays(u, cornell.spheres, cornell.meshes, cornell.triangles, nodes))
+    assert e.value.code == -9
+    # a BVH deeper than the shader's 32-entry stack is rejected, not mis-rendered
+    n = 34
+    deep = np.zeros(2 * n + 1, cornell.nodes.dtype)
+    tris = np.zeros(n + 1, cornell.triangles.dtype)
+    for i in range(n):
+        deep[2 * i]["left"], deep[2 * i]["right"] = 2 * i + 1, 2 * i + 2
+        deep[2 * i + 1]["first"], deep[2 * i + 1]["count"] = i, 1
+    deep[2 * n]["first"], deep[2 * n]["count"] = n, 1
+    mesh = cornell.meshes[:1].copy()
+    mesh["node_offset"], mesh["triangle_offset"], mesh["triangles"] = 0, 0, n + 1
+    u2 = type(u).from_buffer_copy(bytes(u))
+    u2.meshes, u2.nodes = 1, len(deep)
+    with pytest.raises(rt.RtError) as e:
+        t.update_buffers(rt.SceneArrays(u2, cornell.spheres, mesh, tris, deep))
+    assert e.value.code == -5
+    # the scene that was loaded before the failed uploads still renders
+    t.render(rt.make_params(32, 32, 1, 1))
+    t.synchronize()
+    t.close()

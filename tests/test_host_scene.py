@@ -1,0 +1,216 @@
+"""Host-side scene pipeline (C++: OBJ/MTL loader, SAH BVH, scene library)
+against the independent Python restatement oracle/host_oracle.py, against the
+committed Cornell fixture, and against the facts pinned in SURVEY.md 8a."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REFERENCE_ASSETS, ROOT, bits
+
+DATA = os.path.join(ROOT, "tests", "data")
+
+
+def test_tobj_model_splitting_rules(rt):
+    sc = rt.Scene()
+    sc.add_mesh_from_file("quirks.obj", use_mtl=True, assets_dir=DATA)
+    sc.build()
+    # `usemtl` with a new material flushes a model under the *current* name; `g`/`o`
+    # after the faces names the *next* model; pentagon -> 3-triangle fan
+    assert sc.mesh_labels() == ["first", "first", "late_name", "third"]
+    m = sc.meshes()
+    assert m["triangles"].tolist() == [2, 2, 3, 1]
+    red, glassy = m["material"][0], m["material"][1]
+    assert np.allclose(red["color"], [0.9, 0.1, 0.2, 1.0]) and red["flag"] == 0
+    assert red["specular"] == np.float32(0.5) and red["smoothness"] == np.float32(np.sqrt(np.float32(0.64)))
+    assert red["emission_strength"] == np.float32(6.0)          # 2 * max(Ke)
+    assert np.allclose(red["emission_color"], [1.0, 0.5, 0.25, 1.0])
+    assert glassy["flag"] == 1 and glassy["ior"] == np.float32(1.5)   # illum 4 -> GLASS
+    assert glassy["specular"] == np.float32(1.0) and glassy["smoothness"] == 0   # Ks defaults to 1, Ns to 0
+    assert m["material"][2]["flag"] == 1 and m["material"][3]["flag"] == 0
+    t = sc.triangles()
+    # model 0 has vt + vn; its first triangle keeps the file's uv and normal
+    k = int(np.argmin(np.abs(t["v1"][:2] - np.float32([0, 0, 0])).sum(1)))
+    assert t["n1"][k].tolist() == [0, 0, 1]
+    # model 2 (no vn): synthesised normals are unit length
+    tri2 = t[m["triangle_offset"][2]:m["triangle_offset"][2] + 3]
+    assert np.allclose(np.linalg.norm(tri2["n1"], axis=1), 1.0, atol=1e-6)
+
+
+def test_negative_indices_are_relative(rt):
+    sc = rt.Scene()
+    sc.add_mesh_from_file("quirks.obj", use_mtl=False, assets_dir=DATA, mat=rt.material())
+    sc.build()
+    t = sc.triangles()
+    off = sc.meshes()["triangle_offset"][1]
+    zs = np.concatenate([t["v1"][off:off + 2, 2], t["v2"][off:off + 2, 2], t["v3"][off:off + 2, 2]])
+    assert np.all(zs == 1.0)   # `f -3//1 -2//1 -1//1` addressed the three z = 1 vertices
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_ASSETS), reason="reference assets not present")
+def test_cornell_from_assets_matches_fixture_and_survey(rt):
+    sc = rt.Scene.from_name("cornell_box", REFERENCE_ASSETS)
+    arr = rt.SceneArrays.from_scene(sc)
+    fix = rt.SceneArrays.load(os.path.join(GOLDEN, "cornell_scene.npz"))
+    assert arr.meshes.tobytes() == fix.meshes.tobytes()
+    assert arr.triangles.tobytes() == fix.triangles.tobytes()
+    assert arr.nodes.tobytes() == fix.nodes.tobytes()
+    assert bytes(arr.uniform) == bytes(fix.uniform)
+    # 8 tobj models, two of them named leftWall; nodes per mesh 1,1,3,1,3,11,11,1
+    assert sc.mesh_labels() == ["floor", "ceiling", "backWall", "rightWall", "leftWall", "leftWall", "shortBox", "light"]
+    assert arr.meshes["triangles"].tolist() == [2, 2, 2, 2, 2, 10, 10, 2]
+    offs = arr.meshes["node_offset"].tolist() + [32]
+    assert [b - a for a, b in zip(offs, offs[1:])] == [1, 1, 3, 1, 3, 11, 11, 1]
+
+
+def test_cornell_fixture_facts(cornell):
+    u = cornell.uniform
+    assert (u.spheres, u.meshes, u.nodes, u.n_indices) == (0, 8, 32, 96)
+    # view_params = (3.5555556, 2, 1); cam_to_world rotation diag(-1, 1, -1), translation (0, 1, 2)
+    assert list(u.camera.view_params) == [np.float32(3.5555556), 2.0, 1.0]
+    c = np.array([list(col) for col in u.camera.cam_to_world])
+    assert np.array_equal(c[:3, :3], np.diag([-1.0, 1.0, -1.0])) and c[3].tolist() == [0, 1, 2, 1]
+    # every wall specular 0, smoothness sqrt(0.1); light emission (1, 12/17, 4/17) x 34, albedo 0.78
+    m = cornell.meshes["material"]
+    assert np.all(m["specular"] == 0) and np.all(m["smoothness"] == np.float32(np.sqrt(np.float32(0.1))))
+    assert np.all(m["flag"] == 0)
+    assert m["emission_strength"][7] == 34 and np.allclose(m["emission_color"][7], [1, 12 / 17, 4 / 17, 1], atol=1e-7)
+    assert np.allclose(m["color"][7][:3], 0.78)
+    assert np.all(cornell.meshes["model_to_world"] == np.eye(4, dtype=np.float32))
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_ASSETS), reason="reference assets not present")
+def test_loader_against_python_oracle(rt):
+    from oracle import host_oracle as ho
+    models, mats, pos, tex, nrm = ho.load_obj(os.path.join(REFERENCE_ASSETS, "CornellBox-Original.obj"))
+    assert [m["name"] for m in models] == ["floor", "ceiling", "backWall", "rightWall", "leftWall", "leftWall", "shortBox", "light"]
+    fix = rt.SceneArrays.load(os.path.join(GOLDEN, "cornell_scene.npz"))
+    for i, model in enumerate(models):
+        mat = ho.material_from_mtl(mats[model["material_id"]])
+        got = fix.meshes["material"][i]
+        for k, v in mat.items():
+            assert np.array_equal(np.float32(got[k]) if k != "flag" else got[k], np.float32(v) if k != "flag" else v), (i, k)
+        P, N, UV = ho.unroll_model(model, pos, tex, nrm)
+        order, nodes = ho.build_bvh(P)
+        t0 = fix.meshes["triangle_offset"][i]
+        tri = fix.triangles[t0:t0 + len(order)]
+        assert np.array_equal(bits(tri["v1"]), bits(P[order, 0])) and np.array_equal(bits(tri["v3"]), bits(P[order, 2]))
+        assert np.array_equal(bits(tri["n2"]), bits(N[order, 1]))
+        n0 = fix.meshes["node_offset"][i]
+        nd = fix.nodes[n0:n0 + len(nodes)]
+        assert nd["left"].tolist() == [n["left"] for n in nodes] and nd["count"].tolist() == [n["count"] for n in nodes]
+        assert nd["first"].tolist() == [n["first"] for n in nodes]
+        assert np.array_equal(bits(nd["aabb_min"]), bits(np.array([n["mn"] for n in nodes], np.float32)))
+        assert np.array_equal(bits(nd["aabb_max"]), bits(np.array([n["mx"] for n in nodes], np.float32)))
+
+
+@pytest.mark.parametrize("seed,n", [(1, 1), (2, 2), (3, 7), (4, 40), (5, 200)])
+def test_bvh_builder_against_python_oracle_on_random_soups(rt, seed, n):
+    from oracle import host_oracle as ho
+    rng = np.random.RandomState(seed)
+    centre = rng.uniform(-3, 3, (n, 1, 3))
+    P = (centre + rng.uniform(-0.4, 0.4, (n, 3, 3))).astype(np.float32)
+    if seed == 4:
+        P[:, :, 1] = 0.25   # flat soup: one zero-extent axis is skipped (bvh.rs:329-331)
+    v8 = np.zeros((n * 3, 8), np.float32)
+    v8[:, :3] = P.reshape(-1, 3)
+    v8[:, 3:6] = [0, 1, 0]
+    sc = rt.Scene()
+    sc.add_mesh_from_data(v8, np.arange(n * 3))
+    sc.build()
+    order, nodes = ho.build_bvh(P)
+    tri, nd = sc.triangles(), sc.nodes()
+    assert len(nd) == len(nodes)
+    assert np.array_equal(bits(tri["v1"]), bits(P[order, 0]))
+    assert nd["left"].tolist() == [x["left"] for x in nodes] and nd["right"].tolist() == [x["right"] for x in nodes]
+    assert nd["first"].tolist() == [x["first"] for x in nodes] and nd["count"].tolist() == [x["count"] for x in nodes]
+    assert np.array_equal(bits(nd["aabb_min"]), bits(np.array([x["mn"] for x in nodes], np.float32)))
+    # structural invariants: leaves partition the triangles, children boxes inside the parent
+    leaves = nd[nd["count"] > 0]
+    assert sorted(sum([list(range(f, f + c)) for f, c in zip(leaves["first"], leaves["count"])], [])) == list(range(n))
+    for x in nd[nd["count"] == 0]:
+        for c in (nd[x["left"]], nd[x["right"]]):
+            assert np.all(c["aabb_min"] >= x["aabb_min"]) and np.all(c["aabb_max"] <= x["aabb_max"])
+
+
+def test_bvh_quality_modes_and_empty_mesh(rt):
+    v8 = np.zeros((6, 8), np.float32)
+    v8[:, :3] = [[0, 0, 0], [1, 0, 0], [0, 1, 0], [5, 0, 0], [6, 0, 0], [5, 1, 0]]
+    for q, n_nodes in ((1, 3), (0, 3), (2, 1)):   # High, Low split the two far triangles; Disabled keeps the root
+        sc = rt.Scene()
+        sc.add_mesh_from_data(v8, np.arange(6))
+        sc.build(q)
+        assert len(sc.nodes()) == n_nodes
+    sc = rt.Scene()
+    with pytest.raises(rt.RtError):
+        sc.add_mesh_from_data(v8, [0, 1, 9])   # index out of range is a clean error
+
+
+def test_glam_identities(rt):
+    """Transform::cam for the Cornell camera; TRS matrix; inverse."""
+    sc = rt.Scene()
+    sc.set_camera((0, 1, 2), (0, 1, 0))
+    c = np.array([list(col) for col in sc.uniform().camera.cam_to_world])
+    assert np.array_equal(c, np.array([[-1, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, 0], [0, 1, 2, 1]], np.float32))
+    # scale-rotation-translation: columns = (R x)*sx, (R y)*sy, (R z)*sz, (t, 1); 90 deg about Y
+    h = np.float32(np.sqrt(0.5))
+    v8 = np.zeros((3, 8), np.float32)
+    v8[:, :3] = [[0, 0, 0], [1, 0, 0], [0, 1, 0]]
+    sc.add_mesh_from_data(v8, [0, 1, 2], xform=rt.transform(pos=(1, 2, 3), rot=(0, h, 0, h), scale=(2, 3, 4)))
+    sc.build()
+    m = sc.meshes()[0]
+    m2w, w2m = m["model_to_world"].astype(np.float64), m["world_to_model"].astype(np.float64)
+    assert np.allclose(m2w[0][:3], [0, 0, -2], atol=1e-6) and np.allclose(m2w[1][:3], [0, 3, 0], atol=1e-6)
+    assert np.allclose(m2w[2][:3], [4, 0, 0], atol=1e-6) and np.allclose(m2w[3], [1, 2, 3, 1])
+    assert np.allclose(w2m.T @ m2w.T, np.eye(4), atol=1e-6)   # column-major storage: rows here are columns
+
+
+def test_camera_clamps_focus_distance(rt):
+    sc = rt.Scene()
+    sc.set_camera((0, 0, 3), (0, 0, -1), fov=45.0, focus_dist=0.1)   # Camera::new: focus_dist.max(1.0)
+    vp = list(sc.uniform().camera.view_params)
+    assert vp[2] == 1.0 and abs(vp[1] - 2 * np.tan(np.radians(22.5))) < 1e-6 and abs(vp[0] - vp[1] * 16 / 9) < 1e-6
+
+
+def test_builtin_scene_library(rt):
+    counts = {"room": (2, 6), "metal": (4, 0), "balls": (6, 0)}
+    for name, (ns, nm) in counts.items():
+        sc = rt.Scene.from_name(name, DATA)
+        u = sc.uniform()
+        assert (u.spheres, u.meshes) == (ns, nm), name
+    with pytest.raises(rt.RtError):
+        rt.Scene.from_name("no_such_scene", DATA)
+    with pytest.raises(rt.RtError):
+        rt.Scene.from_name("room_2", DATA)   # Dragon_80K.obj is absent: clean error, no abort
+
+
+def test_export_rgba8_matches_save_render_to_file(rt):
+    """app.rs:408-460: gamma 1/2.2, clamp, truncating u8, net vertical flip only."""
+    img = np.zeros((2, 3, 4), np.float32)
+    img[0, 0] = [1.0, 0.5, 0.0, 2.0]
+    img[1, 2] = [0.25, np.nan, -1.0, 1.0]
+    out = np.zeros((2, 3, 4), np.uint8)
+    assert rt.load().rt_export_rgba8(img.ctypes.data, 3, 2, out.ctypes.data) == 0
+    assert out[1, 0].tolist() == [255, int(0.5 ** (1 / 2.2) * 255), 0, 255]
+    assert out[0, 2].tolist() == [int(np.float32(0.25) ** np.float32(1 / 2.2) * 255), 0, 0, 255]
+
+
+def test_png_decoder_and_texture_flip(rt, tmp_path):
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    for mode, shape in (("RGB", (5, 7, 3)), ("RGBA", (4, 3, 4)), ("L", (6, 2)), ("P", (3, 3))):
+        a = rng.randint(0, 256, shape, dtype=np.uint8)
+        im = Image.fromarray(a, mode if mode != "P" else "L")
+        if mode == "P":
+            im = im.convert("P")
+        im.save(tmp_path / "t.png")
+        open(tmp_path / "t.mtl", "w").write("newmtl m\n Kd 1 1 1\n map_Kd t.png\n")
+        open(tmp_path / "t.obj", "w").write("mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl m\nf 1/1 2/2 3/3\n")
+        sc = rt.Scene()
+        sc.add_mesh_from_file("t.obj", assets_dir=str(tmp_path))
+        tex = sc.textures()
+        ref = np.array(Image.open(tmp_path / "t.png").convert("RGBA"))[:, ::-1]   # asset.rs:77 horizontal flip
+        assert len(tex) == 1 and np.array_equal(tex[0], ref), mode
+        sc.build()
+        m = sc.meshes()["material"][0]
+        assert m["flag"] == 2 and m["diffuse_index"] == 0 and m["normal_index"] == -1

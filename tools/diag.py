@@ -38,7 +38,7 @@ def main():
     lib.LIB_PATH = DIAG_SO
     import ray_tracer_2_amd as rt
     variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    W, H = 960, 540
+    W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (960, 540)
     arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
     tr = rt.RayTracer(0, W, H)
     tr.load_scene(arrays)
