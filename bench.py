@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU-staged rehearsal on one GPU)")
     ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning; default: library default)")
     ap.add_argument("--blocks", type=int, default=None, help="persistent grid size (tuning)")
     args = ap.parse_args()
@@ -86,15 +87,19 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()   # > 1 rank per device only in the gloo rehearsal
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     W, H = args.width, args.height
     arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
-    tracer = rt.RayTracer(device=local_rank, max_width=W, max_height=H)
+    tracer = rt.RayTracer(device=device, max_width=W, max_height=H)
     tracer.load_scene(arrays)
     if args.variant is not None:
         tracer.set_option("kernel_variant", args.variant)
@@ -110,9 +115,16 @@ def main():
         gathered = torch.empty((world, pad_texels, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
         frame = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
         assembler = None
+        # everything is ordered on torch's current stream (the one RCCL syncs with):
+        # render -> gather -> assemble, no host synchronisation inside a step
+        side = torch.cuda.Stream()   # a real (non-null) stream; collectives issued under it sync with it
+        torch.cuda.set_stream(side)
+        stream_ptr = side.cuda_stream
+        tracer.set_stream(stream_ptr)
         if rank == 0:
-            assembler = rt.RayTracer(device=local_rank, max_width=8, max_height=8)
+            assembler = rt.RayTracer(device=device, max_width=8, max_height=8)
             assembler.bind_image(frame.data_ptr(), H * W)
+            assembler.set_stream(stream_ptr)
 
     def step(f):
         p = rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=f)
@@ -120,10 +132,15 @@ def main():
             tracer.render(p)
         else:
             tracer.render_strips(p, rank, world)
-            tracer.synchronize()  # render stream -> before the collective reads `local`
-            dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if args.backend == "nccl":
+                dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            else:  # rehearsal: stage through the host
+                host = local.cpu()
+                parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if rank == 0:
+                    gathered.copy_(torch.stack(parts))
             if rank == 0:
-                torch.cuda.current_stream().synchronize()
                 assembler.assemble_strips(gathered.data_ptr(), W, H, world)
 
     def fence():
@@ -144,11 +161,21 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
+    if world > 1 and rank == 0 and os.environ.get("RT2_BENCH_VERIFY"):
+        # the stitched frame must equal the single-GPU frame (same frames sequence)
+        single = rt.RayTracer(device=device, max_width=W, max_height=H)
+        single.load_scene(arrays)
+        for f in range(args.warmup + args.steps):
+            single.render(rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=f))
+        ref = torch.from_numpy(single.read_image(W, H)).reshape(H * W, 4)
+        same = torch.equal(ref.view(torch.int32), frame.cpu().view(torch.int32))
+        print(f"[verify] stitched frame bit-identical to 1-GPU frame: {same}", file=sys.stderr, flush=True)
+        assert same
     st = tracer.stats()
     rays_local = float(st.segments)
     kernel_ms = st.kernel_ms / max(st.launches, 1)
     if world > 1:
-        t = torch.tensor([elapsed, rays_local, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, rays_local, kernel_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

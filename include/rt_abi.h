@@ -230,6 +230,10 @@ int rt_synchronize(rt_handle* h);
 int rt_get_stats(rt_handle* h, rt_stats* out);
 /* Zero the counters and forget the recorded launch times. */
 int rt_reset_timing(rt_handle* h);
+/* Run this handle's work on a caller-owned HIP stream (e.g. the stream a
+ * collective library orders its transfers on) so render -> gather -> assemble
+ * need no host synchronisation; NULL restores the internal stream. */
+int rt_set_stream(rt_handle* h, void* hip_stream);
 /* Render into caller-owned device memory of `texels` RGBA32F texels (e.g. a
  * buffer a collective library will send); NULL restores the internal image. */
 int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);

@@ -29,6 +29,7 @@ using namespace rtd;
 struct rt_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;  // created by rt_create; `stream` may be rebound (rt_set_stream)
     // one (start, stop) event pair per launch since the last rt_reset_timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
@@ -184,7 +185,8 @@ int rt_create(int device_ordinal, uint32_t max_width, uint32_t max_height, rt_ha
     h->max_height = max_height;
     *out = h;
     HIP_TRY(h, hipSetDevice(device_ordinal));
-    HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
     size_t texels = (size_t)max_width * max_height;
     HIP_TRY(h, hipMalloc((void**)&h->own_image, texels * sizeof(float4)));
     h->image = h->own_image;
@@ -220,7 +222,7 @@ void rt_destroy(rt_handle* h) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
 
@@ -569,6 +571,15 @@ int rt_reset_timing(rt_handle* h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(Counters), h->stream));
     h->ev_used = 0;
+    return RT_OK;
+}
+
+int rt_set_stream(rt_handle* h, void* hip_stream) {
+    if (!h) return RT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->ev_used = 0;  // recorded events belong to the old stream's timeline
     return RT_OK;
 }
 

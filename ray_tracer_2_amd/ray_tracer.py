@@ -102,6 +102,9 @@ class RayTracer:
     def reset_timing(self):
         self._check(self._L.rt_reset_timing(self._h))
 
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._L.rt_set_stream(self._h, hip_stream_ptr))
+
     def bind_image(self, device_ptr, texels):
         self._check(self._L.rt_bind_image(self._h, device_ptr, texels))
 
