@@ -321,6 +321,13 @@ const rt_packed_triangle* rt_scene_triangles(const rt_scene* s);
 const rt_node* rt_scene_nodes(const rt_scene* s);
 int rt_scene_get_texture(const rt_scene* s, uint32_t i, rt_texture_desc* out);
 const char* rt_scene_mesh_label(const rt_scene* s, uint32_t i);
+/* Raw (pre-BVH) geometry of mesh instance i, in file order: n_vertices x
+ * (pos[3], normal[3], uv[2]) floats and the index list (≙ MeshData,
+ * geometry/mesh.rs:8-12).  Pass NULL outputs to query the counts. */
+int rt_scene_mesh_data(const rt_scene* s, uint32_t i, float* vertices8, uint32_t* n_vertices,
+                       uint32_t* indices, uint32_t* n_indices, rt_transform* transform,
+                       rt_material* material);
+uint32_t rt_scene_num_mesh_instances(const rt_scene* s);
 const char* rt_scene_last_error(const rt_scene* s);
 void rt_scene_destroy(rt_scene* s);
 

@@ -232,6 +232,34 @@ const char* rt_scene_mesh_label(const rt_scene* s, uint32_t i) {
     return s->scene.meshes[i].label.c_str();
 }
 
+uint32_t rt_scene_num_mesh_instances(const rt_scene* s) { return s ? (uint32_t)s->scene.meshes.size() : 0; }
+
+int rt_scene_mesh_data(const rt_scene* s, uint32_t i, float* v8, uint32_t* n_vertices, uint32_t* indices,
+                       uint32_t* n_indices, rt_transform* t, rt_material* m) {
+    if (!s || i >= s->scene.meshes.size()) return RT_ERR_INVALID_ARGUMENT;
+    const MeshInstance& mi = s->scene.meshes[i];
+    if (n_vertices) *n_vertices = (uint32_t)mi.data->vertices.size();
+    if (n_indices) *n_indices = (uint32_t)mi.data->indices.size();
+    if (v8) {
+        for (size_t k = 0; k < mi.data->vertices.size(); ++k) {
+            const Vertex& v = mi.data->vertices[k];
+            float* p = v8 + k * 8;
+            p[0] = v.pos.x; p[1] = v.pos.y; p[2] = v.pos.z;
+            p[3] = v.normal.x; p[4] = v.normal.y; p[5] = v.normal.z;
+            p[6] = v.uv[0]; p[7] = v.uv[1];
+        }
+    }
+    if (indices) memcpy(indices, mi.data->indices.data(), mi.data->indices.size() * sizeof(uint32_t));
+    if (t) {
+        t->pos[0] = mi.transform.pos.x; t->pos[1] = mi.transform.pos.y; t->pos[2] = mi.transform.pos.z;
+        t->rot[0] = mi.transform.rot.x; t->rot[1] = mi.transform.rot.y; t->rot[2] = mi.transform.rot.z;
+        t->rot[3] = mi.transform.rot.w;
+        t->scale[0] = mi.transform.scale.x; t->scale[1] = mi.transform.scale.y; t->scale[2] = mi.transform.scale.z;
+    }
+    if (m) *m = mi.material;
+    return RT_OK;
+}
+
 const char* rt_scene_last_error(const rt_scene* s) { return s ? s->err.c_str() : "null scene"; }
 
 void rt_scene_destroy(rt_scene* s) { delete s; }

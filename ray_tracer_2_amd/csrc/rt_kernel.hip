@@ -143,6 +143,24 @@ DEV void rand_in_unit_disk(uint32_t& s, float& ox, float& oy) {
     oy = sn * r;
 }
 
+// Camera jitter of wgsl:488,492: rand_in_unit_disk() * strength / size.x.
+// When strength is +0.0 (the default camera) the value is (cos*r)*0/width =
+// +-0 and only the sign of cos / sin survives; the two RNG draws still happen.
+DEV void disk_jitter(uint32_t& s, float strength, float sx, float& jx, float& jy) {
+    if (__float_as_uint(strength) == 0u) {  // wave-uniform
+        float angle = (rand_(s) * 2.0f) * 3.1415926f;
+        bool cn, sn;
+        rtm::trig_signbits(angle, cn, sn);
+        (void)next_random_number(s);  // the radius draw; sqrt(rand) >= +0 cannot change a sign
+        jx = cn ? -0.0f : 0.0f;
+        jy = sn ? -0.0f : 0.0f;
+    } else {
+        rand_in_unit_disk(s, jx, jy);
+        jx = jx * strength / sx;
+        jy = jy * strength / sx;
+    }
+}
+
 // ---- scene memory ----------------------------------------------------------
 extern __shared__ float4 lds_mem[];
 
@@ -588,14 +606,10 @@ DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, ui
     if (s.fresh) {  // wgsl:487-495: next sample of this pixel
         DIAG(1);
         float jx, jy;
-        rand_in_unit_disk(s.rng, jx, jy);
-        jx = jx * a.camera.defocus_strength / c.sx;
-        jy = jy * a.camera.defocus_strength / c.sx;
+        disk_jitter(s.rng, a.camera.defocus_strength, c.sx, jx, jy);
         s.ro = (c.origin + c.right * jx) + c.up * jy;
         float kx, ky;
-        rand_in_unit_disk(s.rng, kx, ky);
-        kx = kx * a.camera.diverge_strength / c.sx;
-        ky = ky * a.camera.diverge_strength / c.sx;
+        disk_jitter(s.rng, a.camera.diverge_strength, c.sx, kx, ky);
         f3 jfp = (s.focus + c.right * kx) + c.up * ky;
         s.rd = normalize3(jfp - s.ro);
         s.rd = normalize3(s.rd);  // wgsl:400

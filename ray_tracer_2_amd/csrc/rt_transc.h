@@ -261,6 +261,24 @@ RT_HD float cos_(float x) {
     return ((t.q + 1) & 2) ? -v : v;
 }
 
+// Sign bits of cos_(x) and sin_(x) for finite x, without evaluating the
+// polynomials: cos_kernel is positive on the reduced interval and sin_kernel(r)
+// has the sign of r (and is +0 for r = +-0), so the signs follow from the
+// quadrant and from r alone.  Used where only the sign of a product with an
+// exact zero survives (rt_kernel.hip, zero-strength camera jitter).
+RT_HD void trig_signbits(float x, bool& cos_neg, bool& sin_neg) {
+    uint32_t ax = f2u(x) & 0x7fffffffu;
+    if (ax < 0x3f490fdau) {
+        cos_neg = false;
+        sin_neg = x < 0.0f;
+        return;
+    }
+    TrigRed t = trig_reduce(x);
+    const bool s_neg = t.r < 0.0f;
+    sin_neg = ((t.q & 1) ? false : s_neg) != ((t.q & 2) != 0);
+    cos_neg = ((t.q & 1) ? s_neg : false) != (((t.q + 1) & 2) != 0);
+}
+
 // ---------------------------------------------------------- atan/acos ----
 RT_HD float atan_pos(float x) {  // x >= 0 finite or +inf
     float y;

@@ -23,7 +23,7 @@ EXPORTS = [
     "rt_scene_add_texture_rgba8", "rt_scene_build", "rt_scene_get_uniform",
     "rt_scene_num_spheres", "rt_scene_num_meshes", "rt_scene_num_triangles", "rt_scene_num_nodes",
     "rt_scene_num_textures", "rt_scene_spheres", "rt_scene_meshes", "rt_scene_triangles",
-    "rt_scene_nodes", "rt_scene_get_texture", "rt_scene_mesh_label", "rt_scene_last_error",
+    "rt_scene_nodes", "rt_scene_get_texture", "rt_scene_mesh_label", "rt_scene_mesh_data", "rt_scene_num_mesh_instances", "rt_scene_last_error",
     "rt_scene_destroy", "rt_upload_built_scene", "rt_scene_subdivide_meshes", "rt_export_rgba8",
 ]
 
@@ -87,6 +87,8 @@ def load():
         "rt_scene_nodes": (vp, [vp]),
         "rt_scene_get_texture": (i32, [vp, u32, P(A.TextureDesc)]),
         "rt_scene_mesh_label": (C.c_char_p, [vp, u32]),
+        "rt_scene_mesh_data": (i32, [vp, u32, vp, P(u32), vp, P(u32), P(A.Transform), P(A.Material)]),
+        "rt_scene_num_mesh_instances": (u32, [vp]),
         "rt_scene_last_error": (C.c_char_p, [vp]),
         "rt_scene_destroy": (None, [vp]),
         "rt_upload_built_scene": (i32, [vp, vp]),

@@ -139,6 +139,20 @@ class Scene:
             out.append(np.frombuffer(buf, dtype=np.uint8).reshape(d.height, d.width, 4).copy())
         return out
 
+    def raw_meshes(self):
+        """[(label, vertices8 [n, 8] f32, indices u32, Transform, Material)] in instance order."""
+        out = []
+        for i in range(self._L.rt_scene_num_mesh_instances(self._p)):
+            nv, ni = C.c_uint32(), C.c_uint32()
+            self._check(self._L.rt_scene_mesh_data(self._p, i, None, C.byref(nv), None, C.byref(ni), None, None))
+            v = np.empty((nv.value, 8), np.float32)
+            idx = np.empty(ni.value, np.uint32)
+            t, m = A.Transform(), A.Material()
+            self._check(self._L.rt_scene_mesh_data(self._p, i, v.ctypes.data, None, idx.ctypes.data, None,
+                                                   C.byref(t), C.byref(m)))
+            out.append((self._L.rt_scene_mesh_label(self._p, i).decode(), v, idx, t, m))
+        return out
+
     def mesh_labels(self):
         return [self._L.rt_scene_mesh_label(self._p, i).decode()
                 for i in range(self._L.rt_scene_num_meshes(self._p))]

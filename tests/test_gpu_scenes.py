@@ -225,3 +225,39 @@ def test_error_codes(rt, tracer, cornell):
     t.render(rt.make_params(32, 32, 1, 1))
     t.synchronize()
     t.close()
+
+
+@pytest.fixture(scope="module")
+def dragon_arrays(rt):
+    """BASELINE config 3 stand-in: dragon.obj x9 subdivision (78,408 triangles) in the Cornell box."""
+    from ray_tracer_2_amd import scenes
+    g = os.path.join(ROOT, "tests", "golden")
+    sc = scenes.cornell_dragon(scenes.load_raw_meshes(os.path.join(g, "cornell_raw.npz")),
+                               scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")), subdivide=3)
+    return rt.SceneArrays.from_scene(sc)
+
+
+def test_config3_dragon_standin(rt, oracle, tracer, dragon_arrays):
+    """BVH far larger than LDS (global-memory scene path), 16 spp, 4 bounces, bit-exact; plus the
+    traversal counters (debug views 5-7 and rt_stats) against the oracle's."""
+    a = dragon_arrays
+    assert a.triangles.shape[0] == 32 + 78408 and a.meshes.shape[0] == 9
+    p = rt.make_params(256, 144, 4, 16, skybox=1, frames=0)
+    tracer.load_scene(a)
+    for variant in (0, 1):
+        tracer.set_option("kernel_variant", variant)
+        tracer.set_counters(True)
+        tracer.reset_timing()
+        tracer.render(p)
+        gpu = tracer.read_image(256, 144)
+        s = tracer.stats()
+        tracer.set_counters(False)
+        ref, st = oracle.render(p, a)
+        assert same(gpu, ref), variant
+        assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests)
+    tracer.set_option("kernel_variant", 0)
+    for dbg in (1, 2, 5, 6, 7):
+        pd = rt.make_params(256, 144, 4, 1, debug_flag=dbg, debug_scale=60)
+        tracer.render(pd)
+        ref, _ = oracle.render(pd, a)
+        assert same(tracer.read_image(256, 144), ref), dbg
