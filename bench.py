@@ -192,6 +192,14 @@ def main():
         texels = local_texels if world > 1 else W * H
         algo_bytes = texels * 16 * 2 + scene_bytes
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
+        # (profiles/run_profile.sh; FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024): PMC counters
+        # cannot be read from inside the process, so the figure is the profiled one or null.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        if world == 1 and (W, H) == (WIDTH, HEIGHT) and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
         out = {
             "metric": "Mrays/s", "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -202,8 +210,8 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"8-row strips round-robin over {world} GPUs + 1 RCCL gather/frame",
                        "rays_per_frame": rays / args.steps, "Mpaths/s": W * H * SPP * args.steps / elapsed / 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "rt_render_kernel<false>", "kernel_ms": kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "rt_render_persistent_kernel<true, false>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "path is FP32-VALU/latency-bound (SURVEY 8d, DESIGN.md): compulsory HBM bytes are ~66 MB/frame"},
         }

@@ -50,6 +50,9 @@ def main():
     if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
         fetch = agg["FETCH_SIZE"] * 1024 * 2  # KiB -> B, gfx950 x2 correction for 16 B/lane reads
         write = agg["WRITE_SIZE"] * 1024
+        import json
+        json.dump({"bytes_per_launch": fetch + write, "source": f"profiles/{tag}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"},
+                  open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "latest_traffic.json"), "w"))
         lines.append(f"HBM traffic per launch: read {fetch / 1e6:.1f} MB (FETCH_SIZE x 1024 x 2) + write {write / 1e6:.1f} MB "
                      f"(WRITE_SIZE x 1024) = {(fetch + write) / 1e6:.1f} MB; algorithmic 66.4 MB")
     if "SQ_INSTS_VALU" in agg and "SQ_WAVES" in agg:

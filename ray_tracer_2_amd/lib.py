@@ -34,6 +34,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and not os.environ.get("RT2_LIB"):
+        # Not a fallback: build the one and only implementation (hipcc cross-compiles gfx950).
+        try:
+            from .build import build_product
+            build_product()
+        except Exception as e:  # noqa: BLE001
+            raise ImportError(f"{LIB_PATH} is missing and could not be built: {e}") from e
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
