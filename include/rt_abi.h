@@ -237,10 +237,11 @@ int rt_set_stream(rt_handle* h, void* hip_stream);
 /* Render into caller-owned device memory of `texels` RGBA32F texels (e.g. a
  * buffer a collective library will send); NULL restores the internal image. */
 int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
-/* Tuning knobs (results never depend on them): "kernel_variant" 0 = persistent
- * waves with active-lane refill (default), 1 = one wave per 8x8 tile;
+/* Tuning knobs (results never depend on them): "kernel_variant" -1 = auto
+ * (default), 0 = persistent waves with active-lane refill, 1 = one wave per 8x8 tile;
  * "persistent_blocks" = grid size of variant 0 (256-thread workgroups);
- * "lds_scene" 0 = never stage the scene into LDS. */
+ * "lds_scene" 0 = never stage the scene into LDS; "tile_feedback" 0 = do not
+ * reorder tiles by the previous frame's per-tile ray counts. */
 int rt_set_option(rt_handle* h, const char* name, int value);
 /* Enable/disable the optional per-ray counters (node/triangle tests). */
 int rt_set_counters(rt_handle* h, int enabled);

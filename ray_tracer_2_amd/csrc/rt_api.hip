@@ -17,6 +17,8 @@
 
 namespace rtd {
 hipError_t launch_render(const RenderArgs& a, hipStream_t stream);
+hipError_t launch_tile_order(const uint32_t* cost, uint32_t n_tiles, uint32_t max_cost, uint32_t* order,
+                             hipStream_t stream);
 hipError_t launch_assemble(const float4* gathered, float4* image, uint32_t width, uint32_t height,
                            uint32_t world, unsigned long long pad_texels, hipStream_t stream);
 #if defined(RT_DIAG)
@@ -41,7 +43,15 @@ struct rt_handle {
     Counters* counters = nullptr;
     uint32_t* work_counters = nullptr;  // ring of per-launch tile counters
     uint32_t work_slot = 0;
-    int kernel_variant = 0;
+    int kernel_variant = -1;  // -1 auto, 0 persistent + lane refill, 1 one wave per tile
+    // tile-cost feedback: rays per tile of the previous frame order the next frame's tiles
+    uint32_t* tile_cost[2] = {nullptr, nullptr};
+    uint32_t* tile_order = nullptr;
+    uint32_t tile_capacity = 0;
+    int cost_slot = 0;
+    bool history_valid = false;
+    uint32_t hist_w = 0, hist_h = 0, hist_rank = 0, hist_world = 0;
+    int tile_feedback = 1;
     uint32_t persistent_blocks = 0;
     float* srgb_lut = nullptr;
     // scene
@@ -195,6 +205,9 @@ int rt_create(int device_ordinal, uint32_t max_width, uint32_t max_height, rt_ha
     HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(Counters)));
     HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(Counters), h->stream));
     HIP_TRY(h, hipMalloc((void**)&h->work_counters, 64 * sizeof(uint32_t)));
+    h->tile_capacity = ((max_width + 7) / 8) * ((max_height + 7) / 8 + 1);
+    for (int k = 0; k < 2; ++k) HIP_TRY(h, hipMalloc((void**)&h->tile_cost[k], (size_t)h->tile_capacity * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc((void**)&h->tile_order, (size_t)h->tile_capacity * sizeof(uint32_t)));
     {
         hipDeviceProp_t prop;
         HIP_TRY(h, hipGetDeviceProperties(&prop, device_ordinal));
@@ -217,6 +230,9 @@ void rt_destroy(rt_handle* h) {
     free_dev(h->own_image);
     free_dev(h->counters);
     free_dev(h->work_counters);
+    free_dev(h->tile_cost[0]);
+    free_dev(h->tile_cost[1]);
+    free_dev(h->tile_order);
     free_dev(h->srgb_lut);
     for (auto& e : h->ev_pool) {
         (void)hipEventDestroy(e.first);
@@ -374,6 +390,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->lds_scene = (uint64_t)lay.bytes + stacks <= LDS_BUDGET_BYTES;
         h->camera = scene->camera;
         h->have_scene = true;
+        h->history_valid = false;
     } catch (const std::bad_alloc&) {
         return fail(h, RT_ERR_OUT_OF_MEMORY, "out of host memory");
     }
@@ -415,11 +432,14 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     if (!h || !name) return RT_ERR_INVALID_ARGUMENT;
     std::string n(name);
     if (n == "kernel_variant") {
-        if (value < 0 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "kernel_variant must be 0 or 1");
+        if (value < -1 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "kernel_variant must be -1 (auto), 0 or 1");
         h->kernel_variant = value;
     } else if (n == "persistent_blocks") {
         if (value < 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "persistent_blocks must be >= 1");
         h->persistent_blocks = (uint32_t)value;
+    } else if (n == "tile_feedback") {
+        h->tile_feedback = value ? 1 : 0;
+        h->history_valid = false;
     } else if (n == "lds_scene") {
         h->force_global = value ? 0 : 1;
     } else {
@@ -471,12 +491,40 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     uint32_t strips = (params->height + 7) / 8;
     a.tiles_y = strips / world + (rank < strips % world ? 1 : 0);
     a.count_tests = (uint32_t)h->count_tests;
-    a.kernel_variant = (uint32_t)h->kernel_variant;
+    // auto: with about one tile per resident wave there is nothing to refill from, and the
+    // plain one-wave-per-tile dispatch is a little faster (tools/strip_scaling.py)
+    const uint32_t resident_waves = h->persistent_blocks * WAVES_PER_BLOCK;
+    a.kernel_variant = h->kernel_variant >= 0 ? (uint32_t)h->kernel_variant
+                                              : ((uint64_t)a.tiles_x * a.tiles_y * 4 <= (uint64_t)resident_waves * 5 ? 1u : 0u);
     a.persistent_blocks = h->persistent_blocks;
     // a fresh tile counter per launch (ring of 64: launches on one stream are ordered)
     h->work_slot = (h->work_slot + 1) & 63u;
     a.work_counter = h->work_counters + h->work_slot;
     HIP_TRY(h, hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), h->stream));
+    // Tile-cost feedback (path-trace frames only): schedule this frame's tiles by the rays each
+    // took in the previous frame of the same shape; record this frame's for the next.
+    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
+    a.tile_order = nullptr;
+    a.tile_cost = nullptr;
+    if (h->tile_feedback && a.kernel_variant == 0 && params->debug_flag == 0 && n_tiles <= h->tile_capacity && n_tiles > 0) {
+        const bool same_shape = h->history_valid && h->hist_w == params->width && h->hist_h == params->height &&
+                                h->hist_rank == rank && h->hist_world == world;
+        if (same_shape) {
+            const long long per_tile = 64ll * (params->rays_per_pixel > 0 ? params->rays_per_pixel : 0) *
+                                       (params->number_of_bounces >= 0 ? params->number_of_bounces + 1 : 0);
+            const uint32_t max_cost = per_tile > 0xffffffffll ? 0xffffffffu : (uint32_t)per_tile;
+            HIP_TRY(h, launch_tile_order(h->tile_cost[h->cost_slot], n_tiles, max_cost, h->tile_order, h->stream));
+            a.tile_order = h->tile_order;
+        }
+        h->cost_slot ^= 1;
+        a.tile_cost = h->tile_cost[h->cost_slot];
+        HIP_TRY(h, hipMemsetAsync(a.tile_cost, 0, (size_t)n_tiles * sizeof(uint32_t), h->stream));
+        h->history_valid = true;
+        h->hist_w = params->width;
+        h->hist_h = params->height;
+        h->hist_rank = rank;
+        h->hist_world = world;
+    }
     if (h->ev_used == h->ev_pool.size()) {
         if (h->ev_pool.size() >= 4096) {
             h->ev_used = 0;  // wrap: only the most recent launches are kept

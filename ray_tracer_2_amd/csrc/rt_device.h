@@ -83,6 +83,8 @@ struct RenderArgs {
     float4* image;  // full frame, or compact strips when strip_world > 1
     Counters* counters;
     uint32_t* work_counter;  // persistent kernel: next 8x8 tile to hand out (zeroed per launch)
+    const uint32_t* tile_order;  // optional: tiles sorted by last frame's cost, heaviest first
+    uint32_t* tile_cost;         // optional: rays per tile of this frame (feeds the next frame's order)
     uint32_t n_meshes, n_spheres, n_textures;
     uint32_t stack_entries;  // per-lane BVH stack depth
     uint32_t strip_rank, strip_world;

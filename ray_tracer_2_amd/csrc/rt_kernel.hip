@@ -571,6 +571,7 @@ struct PixelState {
     f4 T, light;
     int32_t seg;
     bool fresh;
+    uint32_t seg0;         // value of the lane's segment counter when this pixel started
 };
 
 // wgsl:475-484 for pixel (x, y) of the full frame
@@ -594,13 +595,14 @@ DEV void pixel_begin(const RenderArgs& a, const CameraConsts& c, PixelState& s, 
     s.light = f4{0, 0, 0, 0};
     s.ro = f3{0, 0, 0};
     s.rd = f3{0, 0, 1};
+    s.seg0 = 0;
 }
 
 // One iteration of the per-lane state machine: (start the next sample) + one
 // path segment + its shading.  Returns true when the pixel's last sample ended.
 template <bool LDS, bool STATS>
 DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, uint32_t* stack,
-                   unsigned long long& n_segments, int& node_tests, int& tri_tests) {
+                   uint32_t& n_segments, int& node_tests, int& tri_tests) {
     const int32_t nb = a.params.number_of_bounces;
     DIAG(0);
     if (s.fresh) {  // wgsl:487-495: next sample of this pixel
@@ -700,15 +702,18 @@ DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, ui
 }
 
 // wgsl:498 + 154-161
-DEV void pixel_finish(const RenderArgs& a, const PixelState& s) {
+DEV void pixel_finish(const RenderArgs& a, const PixelState& s, uint32_t n_segments) {
     float n = (float)a.params.rays_per_pixel;
     store_texel(a, s.x, s.out_row, f4{s.total.x / n, s.total.y / n, s.total.z / n, s.total.w / n});
+    if (a.tile_cost) {  // rays this pixel took: next frame's tiles are scheduled heaviest first
+        atomicAdd(&a.tile_cost[(s.out_row >> 3) * a.tiles_x + (s.x >> 3)], n_segments - s.seg0);
+    }
 }
 
 template <bool STATS>
-DEV void flush_counters(const RenderArgs& a, unsigned long long n_segments, int node_tests, int tri_tests) {
+DEV void flush_counters(const RenderArgs& a, uint32_t n_segments, int node_tests, int tri_tests) {
     if (a.counters) {
-        atomicAdd(&a.counters->segments, n_segments);
+        atomicAdd(&a.counters->segments, (unsigned long long)n_segments);
         if (STATS) {
             atomicAdd(&a.counters->node_tests, (unsigned long long)node_tests);
             atomicAdd(&a.counters->triangle_tests, (unsigned long long)tri_tests);
@@ -724,19 +729,20 @@ template <bool LDS, bool STATS>
 __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_kernel(const RenderArgs a) {
     uint32_t* stack = block_prologue<LDS>(a);
     const CameraConsts cam = camera_consts(a);
-    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x) * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const bool tile_ok = tile < a.tiles_x * a.tiles_y;
-    const PixelCoord px = pixel_of(a, tile_ok ? tile : 0u, threadIdx.x & 63u);
+    const uint32_t slot = xcd_remap(blockIdx.x, gridDim.x) * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const bool tile_ok = slot < a.tiles_x * a.tiles_y;
+    const uint32_t tile = tile_ok ? (a.tile_order ? a.tile_order[slot] : slot) : 0u;
+    const PixelCoord px = pixel_of(a, tile, threadIdx.x & 63u);
     const bool valid = tile_ok && px.valid;
     PixelState s;
     pixel_begin(a, cam, s, px.x, px.y, px.out_row);
     bool active = valid && a.params.rays_per_pixel > 0;
-    unsigned long long n_segments = 0;
+    uint32_t n_segments = 0;
     int node_tests = 0, tri_tests = 0;
     while (active) {
         if (path_step<LDS, STATS>(a, cam, s, stack, n_segments, node_tests, tri_tests)) active = false;
     }
-    if (valid) pixel_finish(a, s);
+    if (valid) pixel_finish(a, s, n_segments);
     flush_counters<STATS>(a, n_segments, node_tests, tri_tests);
 }
 
@@ -759,7 +765,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
     PixelState s;
     pixel_begin(a, cam, s, 0, 0, 0);
     bool active = false;
-    unsigned long long n_segments = 0;
+    uint32_t n_segments = 0;
     int node_tests = 0, tri_tests = 0;
 
     for (;;) {
@@ -772,6 +778,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                 if (t >= n_tiles) {
                     exhausted = true;
                 } else {
+                    if (a.tile_order) t = a.tile_order[t];  // heaviest tiles first (last frame's cost)
                     pool_base = t * 64u;
                     pool_left = 64u;
                 }
@@ -785,10 +792,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                     if (px.valid) {
                         DIAG(15);
                         pixel_begin(a, cam, s, px.x, px.y, px.out_row);
+                        s.seg0 = n_segments;
                         if (have_samples) {
                             active = true;
                         } else {
-                            pixel_finish(a, s);  // 0 / 0 = NaN, as the shader would store
+                            pixel_finish(a, s, n_segments);  // 0 / 0 = NaN, as the shader would store
                         }
                     }
                 }
@@ -805,7 +813,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         if (active) {
             if (path_step<LDS, STATS>(a, cam, s, stack, n_segments, node_tests, tri_tests)) {
                 DIAG(16);
-                pixel_finish(a, s);
+                pixel_finish(a, s, n_segments);
                 active = false;
             }
         }
@@ -910,6 +918,50 @@ __global__ void rt_assemble_kernel(const float4* __restrict__ gathered, float4* 
     uint32_t strip = y >> 3, ly = y & 7u;
     uint32_t rank = strip % world, ls = strip / world;
     image[i] = gathered[(unsigned long long)rank * pad_texels + (unsigned long long)(ls * 8u + ly) * width + x];
+}
+
+// Tile schedule for the next frame: counting sort of the tiles by the rays
+// they took in the last frame, heaviest first, so that the frame ends on cheap
+// uniform tiles instead of a few long paths (the image never depends on it).
+// One workgroup; n_tiles is a few 10^4.
+constexpr uint32_t ORDER_BINS = 2048;
+__global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t n_tiles,
+                                                               uint32_t max_cost, uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[ORDER_BINS];
+    __shared__ uint32_t chunk_sum[1024 / 64];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < ORDER_BINS; i += 1024) hist[i] = 0;
+    __syncthreads();
+    const unsigned long long scale = max_cost ? max_cost : 1u;
+    auto bin_of = [&](uint32_t c) {
+        unsigned long long b = (unsigned long long)(c < max_cost ? c : max_cost) * (ORDER_BINS - 1) / scale;
+        return (ORDER_BINS - 1) - (uint32_t)b;  // heavy tiles -> low bins -> first
+    };
+    for (uint32_t t = tid; t < n_tiles; t += 1024) atomicAdd(&hist[bin_of(cost[t])], 1u);
+    __syncthreads();
+    // exclusive prefix over the bins: each thread owns 2 consecutive bins
+    uint32_t a0 = hist[2 * tid], a1 = hist[2 * tid + 1];
+    uint32_t mine = a0 + a1, scan = mine;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        uint32_t v = __shfl_up(scan, d);
+        if ((tid & 63u) >= d) scan += v;
+    }
+    if ((tid & 63u) == 63u) chunk_sum[tid >> 6] = scan;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) base += chunk_sum[w];
+    const uint32_t excl = base + scan - mine;
+    __syncthreads();
+    hist[2 * tid] = excl;
+    hist[2 * tid + 1] = excl + a0;
+    __syncthreads();
+    for (uint32_t t = tid; t < n_tiles; t += 1024) order[atomicAdd(&hist[bin_of(cost[t])], 1u)] = t;
+}
+
+hipError_t launch_tile_order(const uint32_t* cost, uint32_t n_tiles, uint32_t max_cost, uint32_t* order,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(rt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, n_tiles, max_cost, order);
+    return hipGetLastError();
 }
 
 #if defined(RT_DIAG)

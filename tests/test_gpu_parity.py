@@ -31,7 +31,7 @@ def loaded(request, tracer, cornell):
     tracer.set_option("kernel_variant", request.param[0])
     tracer.set_option("lds_scene", request.param[1])
     yield tracer
-    tracer.set_option("kernel_variant", 0)
+    tracer.set_option("kernel_variant", -1)
     tracer.set_option("lds_scene", 1)
 
 

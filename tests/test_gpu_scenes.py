@@ -163,7 +163,7 @@ def test_full_size_properties(rt, oracle, tracer, cornell):
         tracer.render(p0)
         assert np.array_equal(bits(tracer.read_image(W, H)), bits(a))
         assert tracer.stats().segments == rays0
-    tracer.set_option("kernel_variant", 0)
+    tracer.set_option("kernel_variant", -1)
     tracer.set_option("lds_scene", 1)
     # (3) accumulation: frame 1 stored = prev*(1-w) + cur*w with cur = the frames=-1 render (same seed)
     tracer.render(rt.make_params(W, H, 4, 8, frames=1))
@@ -255,7 +255,7 @@ def test_config3_dragon_standin(rt, oracle, tracer, dragon_arrays):
         ref, st = oracle.render(p, a)
         assert same(gpu, ref), variant
         assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests)
-    tracer.set_option("kernel_variant", 0)
+    tracer.set_option("kernel_variant", -1)
     for dbg in (1, 2, 5, 6, 7):
         pd = rt.make_params(256, 144, 4, 1, debug_flag=dbg, debug_scale=60)
         tracer.render(pd)

@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ray_tracer_2_amd as rt  # noqa: E402
 
-ALIAS = {"variant": "kernel_variant", "blocks": "persistent_blocks", "lds": "lds_scene"}
-DEFAULTS = {"kernel_variant": 0, "lds_scene": 1}
+ALIAS = {"variant": "kernel_variant", "blocks": "persistent_blocks", "lds": "lds_scene", "fb": "tile_feedback"}
+DEFAULTS = {"kernel_variant": -1, "lds_scene": 1, "tile_feedback": 1}
 
 
 def main():
