@@ -149,11 +149,10 @@ DEV void rand_in_unit_disk(uint32_t& s, float& ox, float& oy) {
 DEV void disk_jitter(uint32_t& s, float strength, float sx, float& jx, float& jy) {
     if (__float_as_uint(strength) == 0u) {  // wave-uniform
         float angle = (rand_(s) * 2.0f) * 3.1415926f;
-        bool cn, sn;
-        rtm::trig_signbits(angle, cn, sn);
+        const uint32_t sb = rtm::trig_signbits(angle);
         (void)next_random_number(s);  // the radius draw; sqrt(rand) >= +0 cannot change a sign
-        jx = cn ? -0.0f : 0.0f;
-        jy = sn ? -0.0f : 0.0f;
+        jx = __uint_as_float((sb & 1u) << 31);  // +-0
+        jy = __uint_as_float((sb & 2u) << 30);
     } else {
         rand_in_unit_disk(s, jx, jy);
         jx = jx * strength / sx;

@@ -266,17 +266,15 @@ RT_HD float cos_(float x) {
 // has the sign of r (and is +0 for r = +-0), so the signs follow from the
 // quadrant and from r alone.  Used where only the sign of a product with an
 // exact zero survives (rt_kernel.hip, zero-strength camera jitter).
-RT_HD void trig_signbits(float x, bool& cos_neg, bool& sin_neg) {
+RT_HD uint32_t trig_signbits(float x) {  // bit 0: cos_(x) negative, bit 1: sin_(x) negative
     uint32_t ax = f2u(x) & 0x7fffffffu;
-    if (ax < 0x3f490fdau) {
-        cos_neg = false;
-        sin_neg = x < 0.0f;
-        return;
-    }
+    if (ax < 0x3f490fdau) return x < 0.0f ? 2u : 0u;
     TrigRed t = trig_reduce(x);
-    const bool s_neg = t.r < 0.0f;
-    sin_neg = ((t.q & 1) ? false : s_neg) != ((t.q & 2) != 0);
-    cos_neg = ((t.q & 1) ? s_neg : false) != (((t.q + 1) & 2) != 0);
+    const uint32_t s_neg = t.r < 0.0f ? 1u : 0u;
+    const uint32_t q = (uint32_t)t.q;
+    const uint32_t sin_neg = ((q & 1u) ? 0u : s_neg) ^ ((q >> 1) & 1u);
+    const uint32_t cos_neg = ((q & 1u) ? s_neg : 0u) ^ (((q + 1u) >> 1) & 1u);
+    return cos_neg | (sin_neg << 1);
 }
 
 // ---------------------------------------------------------- atan/acos ----
