@@ -37,7 +37,7 @@ struct rt_handle {
     size_t ev_used = 0;
     float4* own_image = nullptr;  // allocated by rt_create; `image` may be rebound
     size_t image_texels = 0;
-    int32_t last_spp = 0;
+    unsigned long long paths_total = 0;  // camera paths started since rt_reset_timing
     uint32_t max_width = 0, max_height = 0;
     float4* image = nullptr;
     Counters* counters = nullptr;
@@ -65,9 +65,6 @@ struct rt_handle {
     uint32_t n_meshes = 0, n_spheres = 0, n_textures = 0, n_nodes = 0, n_triangles = 0;
     uint32_t stack_entries = 1;
     rt_camera_uniform camera{};
-    // last render
-    uint32_t last_width = 0, last_height = 0;
-    bool timed = false;
     int count_tests = 0;
     std::string err;
 };
@@ -386,7 +383,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->n_triangles = n_triangles;
         h->stack_entries = max_height ? max_height : 1;
         // LDS residency: blob + the four waves' stacks within the per-workgroup budget
-        uint64_t stacks = (uint64_t)h->stack_entries * 128u * sizeof(uint32_t) * WAVES_PER_BLOCK;
+        uint64_t stacks = (uint64_t)h->stack_entries * 128u * sizeof(uint32_t) * WAVES_PER_BLOCK + 8u * 3u * 4u * WAVES_PER_BLOCK;
         h->lds_scene = (uint64_t)lay.bytes + stacks <= LDS_BUDGET_BYTES;
         h->camera = scene->camera;
         h->have_scene = true;
@@ -506,10 +503,10 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     const uint32_t n_tiles = a.tiles_x * a.tiles_y;
     a.tile_order = nullptr;
     a.tile_cost = nullptr;
-    if (h->tile_feedback && a.kernel_variant == 0 && params->debug_flag == 0 && n_tiles <= h->tile_capacity && n_tiles > 0) {
+    if (h->tile_feedback && params->debug_flag == 0 && n_tiles <= h->tile_capacity && n_tiles > 0) {
         const bool same_shape = h->history_valid && h->hist_w == params->width && h->hist_h == params->height &&
                                 h->hist_rank == rank && h->hist_world == world;
-        if (same_shape) {
+        if (same_shape && a.kernel_variant == 0) {
             const long long per_tile = 64ll * (params->rays_per_pixel > 0 ? params->rays_per_pixel : 0) *
                                        (params->number_of_bounces >= 0 ? params->number_of_bounces + 1 : 0);
             const uint32_t max_cost = per_tile > 0xffffffffll ? 0xffffffffu : (uint32_t)per_tile;
@@ -539,10 +536,15 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     HIP_TRY(h, hipEventRecord(ev.first, h->stream));
     HIP_TRY(h, launch_render(a, h->stream));
     HIP_TRY(h, hipEventRecord(ev.second, h->stream));
-    h->timed = true;
-    h->last_spp = params->rays_per_pixel;
-    h->last_width = params->width;
-    h->last_height = params->height;
+    if (params->debug_flag == 0 && params->rays_per_pixel > 0) {
+        // pixels this call renders (strips are clipped to the image height)
+        unsigned long long rows = 0;
+        for (uint32_t st = rank; st < strips; st += world) {
+            uint32_t y0 = st * 8, y1 = y0 + 8 < params->height ? y0 + 8 : params->height;
+            rows += y1 - y0;
+        }
+        h->paths_total += rows * params->width * (unsigned long long)params->rays_per_pixel;
+    }
     return RT_OK;
 }
 
@@ -559,8 +561,6 @@ int rt_assemble_strips(rt_handle* h, const void* gathered_device, uint32_t width
     HIP_TRY(h, hipSetDevice(h->device));
     unsigned long long pad = rt_strip_texels(width, height, 0, world);
     HIP_TRY(h, launch_assemble((const float4*)gathered_device, h->image, width, height, world, pad, h->stream));
-    h->last_width = width;
-    h->last_height = height;
     return RT_OK;
 }
 
@@ -599,6 +599,7 @@ int rt_get_stats(rt_handle* h, rt_stats* out) {
     HIP_TRY(h, hipMemcpy(&c, h->counters, sizeof(c), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
     out->segments = c.segments;
+    out->paths = h->paths_total;
     out->node_tests = c.node_tests;
     out->triangle_tests = c.triangle_tests;
     // counters accumulate over all launches since rt_reset_timing
@@ -619,6 +620,7 @@ int rt_reset_timing(rt_handle* h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(Counters), h->stream));
     h->ev_used = 0;
+    h->paths_total = 0;
     return RT_OK;
 }
 

@@ -536,6 +536,15 @@ DEV uint32_t* block_prologue(const RenderArgs& a) {
     return reinterpret_cast<uint32_t*>(lds_mem + stack_base) + wave * per_wave + lane;
 }
 
+// The persistent kernel's per-wave tile-cost tables follow the stacks.
+template <bool LDS>
+DEV uint32_t* cost_table_of_wave(const RenderArgs& a) {
+    const uint32_t stack_base = LDS ? (a.lay.bytes >> 4) : 0u;  // float4 units
+    const uint32_t per_wave = (a.stack_entries ? a.stack_entries : 1u) * 128u;
+    return reinterpret_cast<uint32_t*>(lds_mem + stack_base) + WAVES_PER_BLOCK * per_wave +
+           (threadIdx.x >> 6) * (8u * 3u);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -570,7 +579,7 @@ struct PixelState {
     f4 T, light;
     int32_t seg;
     bool fresh;
-    uint32_t seg0;         // value of the lane's segment counter when this pixel started
+    uint32_t meta;         // rays of this pixel so far (bits 0-15, saturating) | cost-table slot (bits 16-18)
 };
 
 // wgsl:475-484 for pixel (x, y) of the full frame
@@ -594,7 +603,7 @@ DEV void pixel_begin(const RenderArgs& a, const CameraConsts& c, PixelState& s, 
     s.light = f4{0, 0, 0, 0};
     s.ro = f3{0, 0, 0};
     s.rd = f3{0, 0, 1};
-    s.seg0 = 0;
+    s.meta = 0;
 }
 
 // One iteration of the per-lane state machine: (start the next sample) + one
@@ -623,6 +632,7 @@ DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, ui
     if (s.seg <= nb) {
         Hit hit = intersect_scene<LDS, STATS>(a, s.ro, s.rd, stack, node_tests, tri_tests);
         n_segments += 1;
+        if ((s.meta & 0xffffu) != 0xffffu) s.meta += 1;
         if (!hit.hit) {
             DIAG(12);
             if (a.params.skybox != 0) s.light = s.light + s.T * environment_light(s.rd);
@@ -701,11 +711,40 @@ DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, ui
 }
 
 // wgsl:498 + 154-161
-DEV void pixel_finish(const RenderArgs& a, const PixelState& s, uint32_t n_segments) {
+DEV void pixel_finish(const RenderArgs& a, const PixelState& s) {
     float n = (float)a.params.rays_per_pixel;
     store_texel(a, s.x, s.out_row, f4{s.total.x / n, s.total.y / n, s.total.z / n, s.total.w / n});
-    if (a.tile_cost) {  // rays this pixel took: next frame's tiles are scheduled heaviest first
-        atomicAdd(&a.tile_cost[(s.out_row >> 3) * a.tiles_x + (s.x >> 3)], n_segments - s.seg0);
+}
+
+// Tile-cost feedback (rays per 8x8 tile, read by the next frame's scheduler).  A persistent
+// wave renders every pixel of the tiles it pulls, so it sums a tile's rays in a small LDS
+// table (8 tiles in flight, 3 dwords each: tile + 1, count << 24 | rays, pixel count) and
+// issues ONE global add per tile; only a tile evicted from the table while still in flight
+// falls back to per-pixel adds.  All updates are adds, so the total is exact either way.
+constexpr uint32_t COST_SLOTS = 8;
+DEV void tile_cost_pull(const RenderArgs& a, uint32_t* tbl, uint32_t slot, uint32_t tile) {
+    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const uint32_t y0 = (ty * a.strip_world + a.strip_rank) * 8u;
+    const uint32_t vx = a.params.width - tx * 8u < 8u ? a.params.width - tx * 8u : 8u;
+    const uint32_t vy = y0 >= a.params.height ? 0u : (a.params.height - y0 < 8u ? a.params.height - y0 : 8u);
+    const uint32_t old = tbl[slot * 3];
+    if (old != 0u) atomicAdd(&a.tile_cost[old - 1u], tbl[slot * 3 + 1] & 0xffffffu);  // evict a straggler
+    tbl[slot * 3] = vx * vy ? tile + 1u : 0u;
+    tbl[slot * 3 + 1] = 0u;
+    tbl[slot * 3 + 2] = vx * vy;
+}
+DEV void tile_cost_add(const RenderArgs& a, uint32_t* tbl, const PixelState& s) {
+    const uint32_t tile = (s.out_row >> 3) * a.tiles_x + (s.x >> 3);
+    const uint32_t rays = s.meta & 0xffffu, slot = (s.meta >> 16) & (COST_SLOTS - 1u);
+    if (tbl[slot * 3] == tile + 1u) {
+        const uint32_t add = (1u << 24) | rays;
+        const uint32_t now = atomicAdd(&tbl[slot * 3 + 1], add) + add;
+        if ((now >> 24) == tbl[slot * 3 + 2]) {  // last pixel of the tile
+            atomicAdd(&a.tile_cost[tile], now & 0xffffffu);
+            tbl[slot * 3] = 0u;
+        }
+    } else {
+        atomicAdd(&a.tile_cost[tile], rays);
     }
 }
 
@@ -741,7 +780,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     while (active) {
         if (path_step<LDS, STATS>(a, cam, s, stack, n_segments, node_tests, tri_tests)) active = false;
     }
-    if (valid) pixel_finish(a, s, n_segments);
+    if (valid) pixel_finish(a, s);
+    if (a.tile_cost && tile_ok) {  // one store per wave: the tile's rays
+        uint32_t sum = n_segments;
+        for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+        if ((threadIdx.x & 63u) == 0u) a.tile_cost[tile] = sum;
+    }
     flush_counters<STATS>(a, n_segments, node_tests, tri_tests);
 }
 
@@ -766,6 +810,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
     bool active = false;
     uint32_t n_segments = 0;
     int node_tests = 0, tri_tests = 0;
+    // this wave's tile-cost table sits behind the workgroup's traversal stacks
+    uint32_t* cost_tbl = cost_table_of_wave<LDS>(a);
+    if (lane < COST_SLOTS * 3u) cost_tbl[lane] = 0u;
+    uint32_t pull_seq = 0;
 
     for (;;) {
         const unsigned long long idle = __ballot(!active);
@@ -780,6 +828,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                     if (a.tile_order) t = a.tile_order[t];  // heaviest tiles first (last frame's cost)
                     pool_base = t * 64u;
                     pool_left = 64u;
+                    pull_seq += 1;
+                    if (a.tile_cost && lane == 0) tile_cost_pull(a, cost_tbl, pull_seq & (COST_SLOTS - 1u), t);
                 }
             }
             if (pool_left != 0) {
@@ -791,11 +841,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                     if (px.valid) {
                         DIAG(15);
                         pixel_begin(a, cam, s, px.x, px.y, px.out_row);
-                        s.seg0 = n_segments;
+                        s.meta = (pull_seq & (COST_SLOTS - 1u)) << 16;
                         if (have_samples) {
                             active = true;
                         } else {
-                            pixel_finish(a, s, n_segments);  // 0 / 0 = NaN, as the shader would store
+                            pixel_finish(a, s);  // 0 / 0 = NaN, as the shader would store
+                            if (a.tile_cost) tile_cost_add(a, cost_tbl, s);
                         }
                     }
                 }
@@ -812,7 +863,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         if (active) {
             if (path_step<LDS, STATS>(a, cam, s, stack, n_segments, node_tests, tri_tests)) {
                 DIAG(16);
-                pixel_finish(a, s, n_segments);
+                pixel_finish(a, s);
+                if (a.tile_cost) tile_cost_add(a, cost_tbl, s);
                 active = false;
             }
         }
@@ -978,7 +1030,8 @@ hipError_t diag_read(unsigned long long* out, bool reset) {
 // Launchers (called from rt_api.hip)
 size_t render_lds_bytes(const RenderArgs& a) {
     size_t stacks = (size_t)(a.stack_entries ? a.stack_entries : 1u) * 128u * sizeof(uint32_t) * WAVES_PER_BLOCK;
-    return stacks + (a.lds_scene ? a.lay.bytes : 0u);
+    size_t cost_tables = 8u * 3u * sizeof(uint32_t) * WAVES_PER_BLOCK;
+    return stacks + cost_tables + (a.lds_scene ? a.lay.bytes : 0u);
 }
 
 template <bool LDS>

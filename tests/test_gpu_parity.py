@@ -56,7 +56,8 @@ def test_config1_frame(rt, oracle, loaded, cornell, sky):
     gpu = loaded.read_image(256, 256)
     ref, st = oracle.render(p, cornell)
     assert_bit_equal(gpu, ref, f"config-1 frame sky={sky}")
-    assert loaded.stats().segments == st.segments
+    s = loaded.stats()
+    assert s.segments == st.segments and s.paths == 256 * 256 and s.launches == 1
     gold = np.load(os.path.join(GOLDEN, "cornell_golden.npz"))[f"frame_256_sky{sky}"]
     assert_bit_equal(gpu, gold, "config-1 frame vs golden")
 

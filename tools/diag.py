@@ -39,7 +39,13 @@ def main():
     import ray_tracer_2_amd as rt
     variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (960, 540)
-    arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
+    if os.environ.get("DIAG_SCENE") == "dragon":
+        from ray_tracer_2_amd import scenes
+        g = os.path.join(ROOT, "tests", "golden")
+        arrays = rt.SceneArrays.from_scene(scenes.cornell_dragon(scenes.load_raw_meshes(os.path.join(g, "cornell_raw.npz")),
+                                                                 scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")), 3))
+    else:
+        arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
     tr = rt.RayTracer(0, W, H)
     tr.load_scene(arrays)
     tr.set_option("kernel_variant", variant)
