@@ -220,6 +220,13 @@ uint64_t rt_strip_texels(uint32_t width, uint32_t height, uint32_t rank, uint32_
 int rt_assemble_strips(rt_handle* h, const void* gathered_device, uint32_t width, uint32_t height,
                        uint32_t world);
 
+/* Single-process multi-GPU frame: per_gpu[r] (one handle per device, same scene
+ * uploaded to each) renders the strips of rank r, per_gpu[0]'s device gathers them
+ * device-to-device over xGMI and assembles the frame; if rgba32f_out is not NULL the
+ * full frame (width*height RGBA32F) is copied there (blocking).  Every handle keeps
+ * its own strip accumulation across frames.  The frame is bit-identical to rt_render's. */
+int rt_render_multi(rt_handle** per_gpu, int n_gpus, const rt_params* params, float* rgba32f_out);
+
 /* ≙ copy_texture_to_buffer in save_render_to_file (app.rs:341-407): blocking
  * copy of width*height RGBA32F texels (row 0 = bottom of the view). */
 int rt_read_image(rt_handle* h, float* rgba32f_out, size_t bytes);

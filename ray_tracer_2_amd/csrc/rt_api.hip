@@ -36,6 +36,10 @@ struct rt_handle {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     float4* own_image = nullptr;  // allocated by rt_create; `image` may be rebound
+    float4* multi_gathered = nullptr;  // rt_render_multi root: [world][pad_texels]
+    float4* multi_frame = nullptr;     // rt_render_multi root: assembled full frame
+    size_t multi_gathered_texels = 0, multi_frame_texels = 0;
+    hipEvent_t multi_event = nullptr;
     size_t image_texels = 0;
     unsigned long long paths_total = 0;  // camera paths started since rt_reset_timing
     uint32_t max_width = 0, max_height = 0;
@@ -225,6 +229,9 @@ void rt_destroy(rt_handle* h) {
     free_scene(h);
     free_textures(h);
     free_dev(h->own_image);
+    free_dev(h->multi_gathered);
+    free_dev(h->multi_frame);
+    if (h->multi_event) (void)hipEventDestroy(h->multi_event);
     free_dev(h->counters);
     free_dev(h->work_counters);
     free_dev(h->tile_cost[0]);
@@ -561,6 +568,69 @@ int rt_assemble_strips(rt_handle* h, const void* gathered_device, uint32_t width
     HIP_TRY(h, hipSetDevice(h->device));
     unsigned long long pad = rt_strip_texels(width, height, 0, world);
     HIP_TRY(h, launch_assemble((const float4*)gathered_device, h->image, width, height, world, pad, h->stream));
+    return RT_OK;
+}
+
+int rt_render_multi(rt_handle** per_gpu, int n_gpus, const rt_params* params, float* rgba32f_out) {
+    if (!per_gpu || n_gpus < 1 || !params) return RT_ERR_INVALID_ARGUMENT;
+    for (int r = 0; r < n_gpus; ++r)
+        if (!per_gpu[r]) return RT_ERR_INVALID_ARGUMENT;
+    rt_handle* root = per_gpu[0];
+    const uint32_t world = (uint32_t)n_gpus;
+    const uint64_t pad = rt_strip_texels(params->width, params->height, 0, world);
+    const uint64_t frame_texels = (uint64_t)params->width * params->height;
+    // root-side staging, grown on demand
+    HIP_TRY(root, hipSetDevice(root->device));
+    if (root->multi_gathered_texels < pad * world) {
+        HIP_TRY(root, hipStreamSynchronize(root->stream));
+        free_dev(root->multi_gathered);
+        HIP_TRY(root, hipMalloc((void**)&root->multi_gathered, pad * world * sizeof(float4)));
+        root->multi_gathered_texels = pad * world;
+    }
+    if (root->multi_frame_texels < frame_texels) {
+        HIP_TRY(root, hipStreamSynchronize(root->stream));
+        free_dev(root->multi_frame);
+        HIP_TRY(root, hipMalloc((void**)&root->multi_frame, frame_texels * sizeof(float4)));
+        root->multi_frame_texels = frame_texels;
+    }
+    // 1. every GPU renders its strips (asynchronous, in parallel across devices)
+    for (int r = 0; r < n_gpus; ++r) {
+        int rc = render_impl(per_gpu[r], params, (uint32_t)r, world);
+        if (rc != RT_OK) {
+            if (per_gpu[r] != root) root->err = "rank " + std::to_string(r) + ": " + per_gpu[r]->err;
+            return rc;
+        }
+    }
+    // 2. gather: the root's stream waits for each rank's render, then pulls its strips
+    //    (device-to-device over xGMI; each peer uses its own link to the root)
+    for (int r = 0; r < n_gpus; ++r) {
+        rt_handle* h = per_gpu[r];
+        // world == 1: the "strips" are the frame itself (no padding of a ragged last strip)
+        const uint64_t n = world == 1 ? frame_texels : rt_strip_texels(params->width, params->height, (uint32_t)r, world);
+        if (n == 0) continue;
+        {
+            HIP_TRY(h, hipSetDevice(h->device));
+            if (!h->multi_event) HIP_TRY(h, hipEventCreateWithFlags(&h->multi_event, hipEventDisableTiming));
+            HIP_TRY(h, hipEventRecord(h->multi_event, h->stream));
+            HIP_TRY(root, hipSetDevice(root->device));
+            HIP_TRY(root, hipStreamWaitEvent(root->stream, h->multi_event, 0));
+        }
+        if (h->device == root->device)
+            HIP_TRY(root, hipMemcpyAsync(root->multi_gathered + (size_t)r * pad, h->image, n * sizeof(float4),
+                                         hipMemcpyDeviceToDevice, root->stream));
+        else
+            HIP_TRY(root, hipMemcpyPeerAsync(root->multi_gathered + (size_t)r * pad, root->device, h->image, h->device,
+                                             n * sizeof(float4), root->stream));
+    }
+    // 3. assemble on the root and (optionally) read back
+    HIP_TRY(root, hipSetDevice(root->device));
+    HIP_TRY(root, launch_assemble(root->multi_gathered, root->multi_frame, params->width, params->height, world, pad,
+                                  root->stream));
+    if (rgba32f_out) {
+        HIP_TRY(root, hipMemcpyAsync(rgba32f_out, root->multi_frame, frame_texels * sizeof(float4),
+                                     hipMemcpyDeviceToHost, root->stream));
+        HIP_TRY(root, hipStreamSynchronize(root->stream));
+    }
     return RT_OK;
 }
 

@@ -123,3 +123,15 @@ class RayTracer:
 
     def strip_texels(self, width, height, rank, world):
         return int(self._L.rt_strip_texels(width, height, rank, world))
+
+
+def render_multi(tracers, params, read_back=True):
+    """rt_render_multi over a list of RayTracer (one per device, same scene on each):
+    returns the assembled frame (H, W, 4) f32 when read_back, else None."""
+    L = load()
+    arr = (C.c_void_p * len(tracers))(*[t._h for t in tracers])
+    out = np.empty((params.height, params.width, 4), np.float32) if read_back else None
+    rc = L.rt_render_multi(arr, len(tracers), C.byref(params), out.ctypes.data if read_back else None)
+    if rc < 0:
+        raise RtError(rc, L.rt_last_error(tracers[0]._h).decode())
+    return out

@@ -140,6 +140,24 @@ def test_strips_assemble_to_the_full_frame(rt, tracer, cornell, world):
     stage.close()
 
 
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_render_multi_single_process(rt, tracer, cornell, n):
+    """rt_render_multi with n handles (all on device 0 here): gather by device-to-device
+    copies + assemble, accumulating over two frames, equals rt_render."""
+    w, h = 168, 100
+    tracer.load_scene(cornell)
+    handles = [rt.RayTracer(0, w, h) for _ in range(n)]
+    for t in handles:
+        t.load_scene(cornell)
+    for f in range(2):
+        p = rt.make_params(w, h, 3, 3, frames=f)
+        tracer.render(p)
+        got = rt.render_multi(handles, p)
+        assert np.array_equal(bits(got), bits(tracer.read_image(w, h))), (n, f)
+    for t in handles:
+        t.close()
+
+
 def test_full_size_properties(rt, oracle, tracer, cornell):
     """BASELINE config 2 at full size (1920x1080, 8 spp, 4 bounces): properties that do
     not need the whole oracle frame."""
