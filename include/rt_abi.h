@@ -189,7 +189,10 @@ int rt_create(int device_ordinal, uint32_t max_width, uint32_t max_height, rt_ha
 
 /* ≙ RayTracer::update_buffers (ray_tracer.rs:397-419), to be called when the
  * scene changes instead of every frame.  All arrays are copied before return.
- * Validates capacities, offsets and BVH depth (<= RT_BVH_STACK - 1). */
+ * Validates capacities and BVH indices (ranges, cycles).  A BVH of height >= 32 --
+ * the shader's 32-entry stack (wgsl:297) can overflow on it -- is accepted and traversed
+ * with the shader's literal push/pop and index clamping, so it renders exactly as the
+ * shader would. */
 int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere* spheres,
                     uint32_t n_spheres, const rt_mesh_uniform* meshes, uint32_t n_meshes,
                     const rt_packed_triangle* triangles, uint32_t n_triangles,

@@ -97,6 +97,13 @@ def trace_pixel(params, arrays, x, y, cap=64):
     return np.array(rgba, dtype=np.float32), rec[:n]
 
 
+def max_stack_index(reset=True):
+    """Largest BVH stack_index seen by renders run with threads=1 since the last reset."""
+    L = load()
+    L.oracle_max_stack_index.restype = C.c_uint32
+    return int(L.oracle_max_stack_index(C.c_int(1 if reset else 0)))
+
+
 def rng_sequence(seed, n):
     L = load()
     s = C.c_uint32(seed)

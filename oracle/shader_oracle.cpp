@@ -272,6 +272,8 @@ static inline float ray_aabb_dist(const Ray& ray, vec3 b_min, vec3 b_max, float 
 }
 
 // wgsl:292-335.  Out-of-range stack indices are clamped (naga "Restrict").
+static thread_local uint32_t g_max_stack_index = 0;  // oracle-only: lets tests see that the stack overflowed
+
 static Hit ray_BVH(const Ctx& c, const Ray& ray, float ray_length, uint32_t node_offset,
                    uint32_t tri_offset, bool cull_backface, int32_t stats[2]) {
     Hit closest_hit;
@@ -314,6 +316,7 @@ static Hit ray_BVH(const Ctx& c, const Ray& ray, float ray_length, uint32_t node
             uint32_t far_idx = !left_is_closer ? child_index_a : child_index_b;
             if (far_dst < closest_hit.dst) { stack[slot(stack_index)] = far_idx; stack_index += 1u; }
             if (near_dst < closest_hit.dst) { stack[slot(stack_index)] = near_idx; stack_index += 1u; }
+            if (stack_index > g_max_stack_index) g_max_stack_index = stack_index;
         }
     }
     return closest_hit;
@@ -644,6 +647,14 @@ int oracle_trace_pixel(const rt_params* params, const rt_scene_uniform* scene, c
                             &segments, st, &tb);
     rgba_out[0] = v.x; rgba_out[1] = v.y; rgba_out[2] = v.z; rgba_out[3] = v.w;
     return (int)tb.n;
+}
+
+// Largest stack_index ray_BVH reached on the calling thread since the last reset (> 32 means
+// the shader's 32-entry stack overflowed and index clamping took effect).
+uint32_t oracle_max_stack_index(int reset) {
+    uint32_t v = orc::g_max_stack_index;
+    if (reset) orc::g_max_stack_index = 0;
+    return v;
 }
 
 uint32_t oracle_next_random_number(uint32_t* state) { return orc::next_random_number(state); }

@@ -17,6 +17,7 @@
 
 namespace rtd {
 hipError_t launch_render(const RenderArgs& a, hipStream_t stream);
+size_t render_lds_bytes(const RenderArgs& a);
 hipError_t launch_tile_order(const uint32_t* cost, uint32_t n_tiles, uint32_t max_cost, uint32_t* order,
                              hipStream_t stream);
 hipError_t launch_assemble(const float4* gathered, float4* image, uint32_t width, uint32_t height,
@@ -267,6 +268,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         struct WideRec { float4 q[4]; };
         std::vector<WideRec> wide;
         std::vector<uint32_t> wide_base(n_meshes), root_idx(n_meshes), root_count(n_meshes);
+        std::vector<char> deep(n_meshes, 0);
         std::vector<uint32_t> wide_index(n_nodes, 0xffffffffu);  // per original node
         uint32_t max_height = 0;
         for (uint32_t i = 0; i < n_meshes; ++i) {
@@ -275,13 +277,14 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             std::string why;
             int rc = mesh_bvh_height(nodes, n_nodes, m.node_offset, m.triangle_offset, n_triangles, height, why);
             if (rc != RT_OK) return fail(h, rc, "mesh " + std::to_string(i) + ": " + why);
-            // The shader's stack holds 32 entries (wgsl:297); with the near
-            // child kept in registers this kernel needs `height` entries and
-            // the shader height + 1.  Deeper trees overflow the shader's
-            // stack (undefined clamped behaviour) and are rejected.
-            if (height + 1 > RT_BVH_STACK)
-                return fail(h, RT_ERR_BVH_DEPTH, "mesh " + std::to_string(i) + ": BVH deeper than the 32-entry traversal stack");
-            if (height > max_height) max_height = height;
+            // The shader's stack holds 32 entries (wgsl:297); with the near child kept in
+            // registers this kernel needs `height` entries and the shader height + 1.  A
+            // tree of height >= 32 can overflow the shader's stack; such a mesh is traversed
+            // with the shader's literal push/pop and clamped indices (DMESH_DEEP), which
+            // needs the full 32 entries.
+            deep[i] = height + 1 > RT_BVH_STACK;
+            const uint32_t need = deep[i] ? RT_BVH_STACK : height;
+            if (need > max_height) max_height = need;
             // Wide records: internal nodes in DFS pre-order, indexed per mesh.
             // (Meshes may alias node ranges; records are built per mesh.)
             wide_base[i] = (uint32_t)wide.size();
@@ -348,6 +351,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             uint32_t flags = 0;
             if (i > 0 && memcmp(m.world_to_model, meshes[i - 1].world_to_model, 64) == 0) flags |= DMESH_SAME_XFORM;
             if (m.material.flag == RT_MATERIAL_GLASS) flags |= DMESH_GLASS;
+            if (deep[i]) flags |= DMESH_DEEP;
             r[8] = make_float4(asf(flags), asf(root_idx[i]), asf(root_count[i]), asf(m.triangle_offset));
             r[9] = make_float4(asf(wide_base[i]), 0.0f, 0.0f, 0.0f);
             memcpy(blob.data() + (lay.mat_off + (size_t)i * MATERIAL_BYTES) / 16, &m.material, MATERIAL_BYTES);
@@ -501,6 +505,15 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.kernel_variant = h->kernel_variant >= 0 ? (uint32_t)h->kernel_variant
                                               : ((uint64_t)a.tiles_x * a.tiles_y * 4 <= (uint64_t)resident_waves * 5 ? 1u : 0u);
     a.persistent_blocks = h->persistent_blocks;
+    {
+        // workgroups that fit a CU's 160 KiB of LDS (4 when the register budget is the limit)
+        const size_t lds = render_lds_bytes(a);
+        uint32_t per_cu = lds ? (uint32_t)((160u * 1024u) / lds) : 4u;
+        if (per_cu > 4u) per_cu = 4u;
+        if (per_cu < 1u) per_cu = 1u;
+        const uint32_t fit = (h->persistent_blocks / 4u) * per_cu;
+        if (fit < a.persistent_blocks && fit > 0) a.persistent_blocks = fit;
+    }
     // a fresh tile counter per launch (ring of 64: launches on one stream are ordered)
     h->work_slot = (h->work_slot + 1) & 63u;
     a.work_counter = h->work_counters + h->work_slot;

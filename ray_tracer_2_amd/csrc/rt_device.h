@@ -37,6 +37,8 @@ constexpr uint32_t MESH_REC_BYTES = 160;
 enum : uint32_t {
     DMESH_SAME_XFORM = 1u,  // world_to_model bit-identical to the previous mesh's
     DMESH_GLASS = 2u,       // material.flag == GLASS  => no backface culling (wgsl:375)
+    DMESH_DEEP = 4u,        // BVH height >= 32: the shader's 32-entry stack can overflow; traverse it
+                            // with the shader's literal push/pop and index clamping (naga Restrict)
 };
 // Wide BVH record of one internal node (both children's boxes inline, so a
 // visit is one round trip instead of three dependent ones), 4 x 16 B:

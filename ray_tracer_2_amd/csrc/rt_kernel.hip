@@ -254,7 +254,7 @@ DEV float aabb_dist(f3 lo, f3 inv, float4 bmin, float4 bmax, float t) {
 // leaf, then the wave tests leaf triangles together.
 template <bool LDS, bool STATS>
 DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_count, uint32_t tri_base,
-                       uint32_t wide_base, bool cull, f3 lo, f3 ld, f3 inv, uint32_t* stack,
+                       uint32_t wide_base, bool cull, bool deep, f3 lo, f3 ld, f3 inv, uint32_t* stack,
                        MeshBest& best, int& node_tests, int& tri_tests) {
     const uint32_t tri0 = a.lay.tri_off + tri_base * TRI_ISECT_BYTES;
     if (root_count > 0) {
@@ -267,6 +267,47 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
         return;
     }
     const uint32_t wide0 = a.lay.wide_off + wide_base * WIDE_REC_BYTES;
+    if (deep) {
+        // BVH of height >= 32: the shader's `array<u32,32>` stack can overflow, and what it
+        // then does is defined by naga's Restrict policy (out-of-range indices are clamped to
+        // 31 while stack_index keeps counting).  Reproduce wgsl:297-333 literally.
+        auto slot = [](uint32_t i) { return (i < RT_BVH_STACK ? i : RT_BVH_STACK - 1u) * 128u; };
+        uint32_t stack_index = 0;
+        stack[slot(0)] = root_idx;
+        stack[slot(0) + 64] = 0u;
+        stack_index = 1;
+        while (stack_index > 0) {
+            stack_index -= 1;
+            const uint32_t idx = stack[slot(stack_index)], cnt = stack[slot(stack_index) + 64];
+            if (cnt > 0) {
+                if (STATS) tri_tests += (int)cnt;
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const uint32_t t = tri0 + (idx + j) * TRI_ISECT_BYTES;
+                    tri_test<8>(lo, ld, ld4<LDS>(a, t), ld4<LDS>(a, t + 16), ld4<LDS>(a, t + 32), cull, idx + j, best);
+                }
+            } else {
+                const uint32_t wo = wide0 + idx * WIDE_REC_BYTES;
+                const float4 q0 = ld4<LDS>(a, wo), q1 = ld4<LDS>(a, wo + 16), q2 = ld4<LDS>(a, wo + 32),
+                             q3 = ld4<LDS>(a, wo + 48);
+                float da = aabb_dist(lo, inv, q0, q1, best.t);
+                float db = aabb_dist(lo, inv, q2, q3, best.t);
+                if (STATS) node_tests += 2;
+                const bool left_closer = da < db;
+                const float near_d = left_closer ? da : db, far_d = left_closer ? db : da;
+                if (far_d < best.t) {
+                    stack[slot(stack_index)] = fbits(left_closer ? q2.w : q0.w);
+                    stack[slot(stack_index) + 64] = fbits(left_closer ? q3.w : q1.w);
+                    stack_index += 1;
+                }
+                if (near_d < best.t) {
+                    stack[slot(stack_index)] = fbits(left_closer ? q0.w : q2.w);
+                    stack[slot(stack_index) + 64] = fbits(left_closer ? q1.w : q3.w);
+                    stack_index += 1;
+                }
+            }
+        }
+        return;
+    }
     uint32_t cur = root_idx, cur_count = 0, sp = 0;
     for (;;) {
         bool finished = false;
@@ -381,7 +422,8 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         b.u = b.v = b.w = b.det = 0.0f;
         const uint32_t wide_base = fbits(ld4<LDS>(a, mo + 144).x);
         traverse_mesh<LDS, STATS>(a, fbits(hdr.y), fbits(hdr.z), fbits(hdr.w), wide_base,
-                                  (flags & DMESH_GLASS) == 0, lo, ld, inv, stack, b, node_tests, tri_tests);
+                                  (flags & DMESH_GLASS) == 0, (flags & DMESH_DEEP) != 0, lo, ld, inv, stack, b,
+                                  node_tests, tri_tests);
         if (b.tri != 0xffffffffu) {
             DIAG(10);
             const float4 c0 = ld4<LDS>(a, mo + 64), c1 = ld4<LDS>(a, mo + 80), c2 = ld4<LDS>(a, mo + 96),
@@ -1034,23 +1076,27 @@ size_t render_lds_bytes(const RenderArgs& a) {
     return stacks + cost_tables + (a.lds_scene ? a.lay.bytes : 0u);
 }
 
+// Dynamic LDS above 64 KiB (deep-BVH stacks) has to be opted into per kernel.
+template <typename K>
+static void launch_k(K kernel, uint32_t blocks, size_t lds, hipStream_t stream, const RenderArgs& a) {
+    if (lds > 64u * 1024u) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), lds, stream, a);
+}
+
 template <bool LDS>
 static void launch_variant(const RenderArgs& a, uint32_t ntiles, size_t lds, hipStream_t stream) {
     const uint32_t tile_blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (a.params.debug_flag != 0) {
-        hipLaunchKernelGGL(rt_debug_kernel<LDS>, dim3(tile_blocks), dim3(BLOCK_THREADS), lds, stream, a);
+        launch_k(rt_debug_kernel<LDS>, tile_blocks, lds, stream, a);
     } else if (a.kernel_variant == 1) {
-        if (a.count_tests)
-            hipLaunchKernelGGL((rt_render_tiles_kernel<LDS, true>), dim3(tile_blocks), dim3(BLOCK_THREADS), lds, stream, a);
-        else
-            hipLaunchKernelGGL((rt_render_tiles_kernel<LDS, false>), dim3(tile_blocks), dim3(BLOCK_THREADS), lds, stream, a);
+        if (a.count_tests) launch_k(rt_render_tiles_kernel<LDS, true>, tile_blocks, lds, stream, a);
+        else launch_k(rt_render_tiles_kernel<LDS, false>, tile_blocks, lds, stream, a);
     } else {
         uint32_t blocks = a.persistent_blocks < tile_blocks ? a.persistent_blocks : tile_blocks;
         if (blocks == 0) blocks = 1;
-        if (a.count_tests)
-            hipLaunchKernelGGL((rt_render_persistent_kernel<LDS, true>), dim3(blocks), dim3(BLOCK_THREADS), lds, stream, a);
-        else
-            hipLaunchKernelGGL((rt_render_persistent_kernel<LDS, false>), dim3(blocks), dim3(BLOCK_THREADS), lds, stream, a);
+        if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true>, blocks, lds, stream, a);
+        else launch_k(rt_render_persistent_kernel<LDS, false>, blocks, lds, stream, a);
     }
 }
 

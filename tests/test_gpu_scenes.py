@@ -224,21 +224,6 @@ def test_error_codes(rt, tracer, cornell):
     with pytest.raises(rt.RtError) as e:
         t.update_buffers(rt.SceneArrays(u, cornell.spheres, cornell.meshes, cornell.triangles, nodes))
     assert e.value.code == -9
-    # a BVH deeper than the shader's 32-entry stack is rejected, not mis-rendered
-    n = 34
-    deep = np.zeros(2 * n + 1, cornell.nodes.dtype)
-    tris = np.zeros(n + 1, cornell.triangles.dtype)
-    for i in range(n):
-        deep[2 * i]["left"], deep[2 * i]["right"] = 2 * i + 1, 2 * i + 2
-        deep[2 * i + 1]["first"], deep[2 * i + 1]["count"] = i, 1
-    deep[2 * n]["first"], deep[2 * n]["count"] = n, 1
-    mesh = cornell.meshes[:1].copy()
-    mesh["node_offset"], mesh["triangle_offset"], mesh["triangles"] = 0, 0, n + 1
-    u2 = type(u).from_buffer_copy(bytes(u))
-    u2.meshes, u2.nodes = 1, len(deep)
-    with pytest.raises(rt.RtError) as e:
-        t.update_buffers(rt.SceneArrays(u2, cornell.spheres, mesh, tris, deep))
-    assert e.value.code == -5
     # the scene that was loaded before the failed uploads still renders
     t.render(rt.make_params(32, 32, 1, 1))
     t.synchronize()
@@ -279,3 +264,101 @@ def test_config3_dragon_standin(rt, oracle, tracer, dragon_arrays):
         tracer.render(pd)
         ref, _ = oracle.render(pd, a)
         assert same(tracer.read_image(256, 144), ref), dbg
+
+
+def deep_chain_scene(rt, cornell, levels=36, trap=31):
+    """A hand-built chain BVH `levels` deep.  Levels 0..trap-1: the leaf is a far triangle and
+    the other child (the rest of the chain) is nearer, so every level leaves a pending far entry
+    and the shader's 32-entry stack fills up.  At level `trap` the leaf's box is nearer but its
+    triangle is off to the side, so with an overflowing stack (far = rest of the chain, written
+    to slot 31 and overwritten by the near leaf) the nearer triangles below are never tested."""
+    n = levels
+    tris = np.zeros(n + 1, cornell.triangles.dtype)
+    z = np.zeros(n + 1, np.float32)
+    for k in range(n + 1):
+        z[k] = -100.0 - k if k < trap else (-10.0 if k == trap else -20.0 - (k - trap))
+    for k in range(n + 1):
+        v1, v2, v3 = (-10, -10, z[k]), (10, -10, z[k]), (0, 10, z[k])
+        if k == trap:
+            v1, v2, v3 = (-10, -10, z[k]), (-9, -10, z[k]), (-10, -9, z[k])   # far from every camera ray
+        tris[k]["v1"], tris[k]["v2"], tris[k]["v3"] = v1, v2, v3
+        tris[k]["n1"] = tris[k]["n2"] = tris[k]["n3"] = (0, 0, 1)
+    nodes = np.zeros(2 * n + 1, cornell.nodes.dtype)
+    big_lo, big_hi = np.float32([-10, -10, 0]), np.float32([10, 10, 0])
+    for k in range(n):
+        internal, leaf = 2 * k, 2 * k + 1
+        nodes[internal]["left"], nodes[internal]["right"] = leaf, 2 * k + 2
+        zs = z[k:]
+        nodes[internal]["aabb_min"] = (-10, -10, zs.min())
+        nodes[internal]["aabb_max"] = (10, 10, zs.max())
+        nodes[leaf]["first"], nodes[leaf]["count"] = k, 1
+        nodes[leaf]["aabb_min"] = big_lo + np.float32([0, 0, z[k]])   # box of the full-size triangle, also for the trap
+        nodes[leaf]["aabb_max"] = big_hi + np.float32([0, 0, z[k]])
+    last = 2 * n
+    nodes[last]["first"], nodes[last]["count"] = n, 1
+    nodes[last]["aabb_min"], nodes[last]["aabb_max"] = big_lo + np.float32([0, 0, z[n]]), big_hi + np.float32([0, 0, z[n]])
+    sc = rt.Scene()
+    sc.set_camera((0, 0, 5), (0, 0, 0), fov=30.0)
+    mesh = cornell.meshes[:1].copy()
+    mesh["node_offset"], mesh["triangle_offset"], mesh["triangles"] = 0, 0, n + 1
+    mesh["material"]["color"] = (0.8, 0.7, 0.6, 1.0)
+    mesh["material"]["emission_strength"] = 0.5
+    mesh["material"]["emission_color"] = (1, 1, 1, 1)
+    u = sc.uniform()
+    u.meshes, u.nodes, u.spheres = 1, len(nodes), 0
+    return rt.SceneArrays(u, np.zeros(0, cornell.spheres.dtype), mesh, tris, nodes)
+
+
+@pytest.mark.parametrize("levels,trap,expect_overflow,expect_depth",
+                         [(31, 31, False, 105.0), (36, 20, False, 26.0), (32, 31, True, 105.0),
+                          (36, 31, True, 105.0), (45, 31, True, 105.0)])
+def test_deep_bvh_reproduces_the_shader_stack_overflow(rt, oracle, tracer, cornell, levels, trap,
+                                                       expect_overflow, expect_depth):
+    """BVH height >= 32: wgsl:297's 32-entry stack can overflow and naga's index clamping decides
+    what is traversed.  The HIP path must make the same (wrong) choices, bit for bit: with the
+    trap at level 31 the image centre sees depth 105 (the far triangles) although a triangle at
+    depth 26 exists further down the chain; with the trap at level 20 the stack never fills and
+    the depth is 26."""
+    a = deep_chain_scene(rt, cornell, levels, trap)
+    tracer.load_scene(a)
+    oracle.max_stack_index()
+    for dbg, spp in ((2, 1), (5, 1), (6, 1), (0, 3)):
+        p = rt.make_params(64, 40, 3, spp, skybox=1, frames=0, debug_flag=dbg, debug_scale=200)
+        tracer.render(p)
+        ref, _ = oracle.render(p, a, threads=1)
+        assert same(tracer.read_image(64, 40), ref), (levels, dbg)
+    assert (oracle.max_stack_index() > 32) == expect_overflow
+    p = rt.make_params(65, 41, 0, 1, debug_flag=2, debug_scale=1)
+    tracer.render(p)
+    assert abs(tracer.read_image(65, 41)[20, 32, 0] - expect_depth) < 0.5
+
+
+def test_config5_geometry_standin(rt, oracle, tracer):
+    """BASELINE config 5 geometry stand-in: dragon.obj split 11 x 11 = 1,054,152 triangles (under the
+    1,375,000 cap) in the Cornell box; its BVH is 32+ levels deep, so the literal-stack mode is used.
+    Small image, bit-exact including the traversal counters."""
+    from ray_tracer_2_amd import scenes
+    g = os.path.join(ROOT, "tests", "golden")
+    sc = scenes.cornell_dragon(scenes.load_raw_meshes(os.path.join(g, "cornell_raw.npz")),
+                               scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")), subdivide=11)
+    a = rt.SceneArrays.from_scene(sc)
+    assert a.triangles.shape[0] == 32 + 1054152 and a.nodes.shape[0] <= 2600000
+    big = rt.RayTracer(0, 3840, 2160)   # the reference's 1920x1080 texture cap is lifted
+    big.load_scene(a)
+    p = rt.make_params(160, 90, 8, 2, skybox=1, frames=0)
+    big.set_counters(True)
+    big.reset_timing()
+    big.render(p)
+    gpu, s = big.read_image(160, 90), big.stats()
+    ref, st = oracle.render(p, a)
+    assert same(gpu, ref)
+    assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests)
+    # a 4K frame fits and runs (config 5's 3840x2160)
+    big.set_counters(False)
+    big.render(rt.make_params(3840, 2160, 8, 1, skybox=1, frames=0))
+    img = big.read_image(3840, 2160)
+    rows = np.array([5, 1080, 2159], np.uint32)
+    ref4k = np.zeros((2160, 3840, 4), np.float32)
+    oracle.render(rt.make_params(3840, 2160, 8, 1, skybox=1, frames=0), a, image=ref4k, rows=rows)
+    assert np.array_equal(bits(img[rows]), bits(ref4k[rows]))
+    big.close()
