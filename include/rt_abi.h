@@ -250,7 +250,9 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
 /* Tuning knobs (results never depend on them): "kernel_variant" -1 = auto
  * (default), 0 = persistent waves with active-lane refill, 1 = one wave per 8x8 tile;
  * "persistent_blocks" = grid size of variant 0 (256-thread workgroups);
- * "lds_scene" 0 = never stage the scene into LDS; "tile_feedback" 0 = do not
+ * "lds_scene" 0 = never stage the scene into LDS; "cull_roots" -1 auto / 0 / 1 =
+ * results-preserving root-box culling of meshes in the mesh loop; "tlas" 0 = no top-level
+ * trees over mesh root boxes (takes effect at the next rt_upload_scene); "tile_feedback" 0 = do not
  * reorder tiles by the previous frame's per-tile ray counts. */
 int rt_set_option(rt_handle* h, const char* name, int value);
 /* Enable/disable the optional per-ray counters (node/triangle tests). */

@@ -7,7 +7,10 @@
 // aborts across the boundary).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cfloat>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -64,11 +67,14 @@ struct rt_handle {
     float4* blob = nullptr;  // the scene, see rt_device.h
     SceneLayout lay{};
     bool lds_scene = false;
+    bool roots_are_unions = false;  // every internal root's box is the exact union of its children's
+    int cull_roots = -1;            // option: -1 auto (many meshes), 0 off, 1 on (if provable)
     int force_global = 0;  // option "lds_scene" = 0 disables LDS staging (tuning / tests)
     DTexture* textures = nullptr;
     std::vector<uint8_t*> texture_data;
     uint32_t n_meshes = 0, n_spheres = 0, n_textures = 0, n_nodes = 0, n_triangles = 0;
-    uint32_t stack_entries = 1;
+    uint32_t stack_entries = 1, tlas_entries = 0, n_items = 0;
+    int use_tlas = 1;  // option "tlas": 0 = every mesh is a single item (takes effect at the next upload)
     rt_camera_uniform camera{};
     int count_tests = 0;
     std::string err;
@@ -329,6 +335,104 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 wide.push_back(w);
             }
         }
+        // ---- mesh-loop items and top-level trees -------------------------------------
+        // Runs of consecutive meshes with bit-identical world_to_model share a local space.
+        // Within a run, meshes with an internal, non-deep root whose box provably contains its
+        // children's go under a TLAS when there are enough of them; every other mesh is a
+        // single item.  (Visit order is free: rt_kernel.hip breaks distance ties by mesh index.)
+        struct Item { uint32_t kind, a, b, n; };
+        std::vector<Item> items;
+        std::vector<WideRec> tlas;
+        uint32_t tlas_depth = 0;
+        auto root_box_ok = [&](uint32_t i) {
+            const rt_node* mn = nodes + meshes[i].node_offset;
+            if (mn[0].count > 0 || deep[i]) return false;
+            const rt_node &ca = mn[mn[0].left], &cb = mn[mn[0].right];
+            for (int k = 0; k < 3; ++k) {
+                const float lo_k = ca.aabb_min[k] < cb.aabb_min[k] ? ca.aabb_min[k] : cb.aabb_min[k];
+                const float hi_k = ca.aabb_max[k] > cb.aabb_max[k] ? ca.aabb_max[k] : cb.aabb_max[k];
+                if (!(mn[0].aabb_min[k] <= lo_k && mn[0].aabb_max[k] >= hi_k)) return false;
+                if (!(ca.aabb_min[k] <= ca.aabb_max[k] && cb.aabb_min[k] <= cb.aabb_max[k])) return false;
+                if (!(mn[0].aabb_min[k] - mn[0].aabb_min[k] == 0.0f && mn[0].aabb_max[k] - mn[0].aabb_max[k] == 0.0f)) return false;  // finite
+            }
+            return true;
+        };
+        struct Box { float lo[3], hi[3]; };
+        auto asf2 = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+        // recursive median split over root-box centroids; returns the child reference (idx, count)
+        std::function<void(std::vector<uint32_t>&, size_t, size_t, uint32_t, uint32_t&, uint32_t&, Box&)> build_tlas =
+            [&](std::vector<uint32_t>& ms, size_t b0, size_t e0, uint32_t depth, uint32_t& idx, uint32_t& cnt, Box& box) {
+                if (depth > tlas_depth) tlas_depth = depth;
+                if (e0 - b0 == 1) {
+                    const rt_node& r = nodes[meshes[ms[b0]].node_offset];
+                    for (int k = 0; k < 3; ++k) { box.lo[k] = r.aabb_min[k]; box.hi[k] = r.aabb_max[k]; }
+                    idx = ms[b0];
+                    cnt = 1;
+                    return;
+                }
+                float cmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                for (size_t q = b0; q < e0; ++q) {
+                    const rt_node& r = nodes[meshes[ms[q]].node_offset];
+                    for (int k = 0; k < 3; ++k) {
+                        float c = 0.5f * r.aabb_min[k] + 0.5f * r.aabb_max[k];
+                        if (c < cmin[k]) cmin[k] = c;
+                        if (c > cmax[k]) cmax[k] = c;
+                    }
+                }
+                int axis = 0;
+                if (cmax[1] - cmin[1] > cmax[axis] - cmin[axis]) axis = 1;
+                if (cmax[2] - cmin[2] > cmax[axis] - cmin[axis]) axis = 2;
+                std::sort(ms.begin() + b0, ms.begin() + e0, [&](uint32_t x, uint32_t y) {
+                    const rt_node &rx = nodes[meshes[x].node_offset], &ry = nodes[meshes[y].node_offset];
+                    float cx = rx.aabb_min[axis] + rx.aabb_max[axis], cy = ry.aabb_min[axis] + ry.aabb_max[axis];
+                    return cx < cy || (cx == cy && x < y);
+                });
+                const size_t mid = b0 + (e0 - b0) / 2;
+                const uint32_t me = (uint32_t)tlas.size();
+                tlas.emplace_back();
+                uint32_t ai, ac, bi, bc;
+                Box ba, bb;
+                build_tlas(ms, b0, mid, depth + 1, ai, ac, ba);
+                build_tlas(ms, mid, e0, depth + 1, bi, bc, bb);
+                WideRec w;
+                w.q[0] = make_float4(ba.lo[0], ba.lo[1], ba.lo[2], asf2(ai));
+                w.q[1] = make_float4(ba.hi[0], ba.hi[1], ba.hi[2], asf2(ac));
+                w.q[2] = make_float4(bb.lo[0], bb.lo[1], bb.lo[2], asf2(bi));
+                w.q[3] = make_float4(bb.hi[0], bb.hi[1], bb.hi[2], asf2(bc));
+                tlas[me] = w;
+                for (int k = 0; k < 3; ++k) {  // exact union (min/max are exact)
+                    box.lo[k] = ba.lo[k] < bb.lo[k] ? ba.lo[k] : bb.lo[k];
+                    box.hi[k] = ba.hi[k] > bb.hi[k] ? ba.hi[k] : bb.hi[k];
+                }
+                idx = me;
+                cnt = 0;
+            };
+        for (uint32_t i0 = 0; i0 < n_meshes;) {
+            uint32_t i1 = i0 + 1;
+            while (i1 < n_meshes && memcmp(meshes[i1].world_to_model, meshes[i0].world_to_model, 64) == 0) ++i1;
+            std::vector<uint32_t> grouped;
+            if (h->use_tlas)
+                for (uint32_t i = i0; i < i1; ++i)
+                    if (root_box_ok(i)) grouped.push_back(i);
+            if (grouped.size() < TLAS_MIN_MESHES) grouped.clear();
+            bool first = true;
+            auto flag = [&]() { uint32_t f = first ? ITEM_NEW_XFORM : 0u; first = false; return f; };
+            size_t g = 0;
+            for (uint32_t i = i0; i < i1; ++i) {
+                if (g < grouped.size() && grouped[g] == i) { ++g; continue; }
+                items.push_back(Item{flag(), i, i0, 1});
+            }
+            if (!grouped.empty()) {
+                std::vector<uint32_t> ms = grouped;
+                uint32_t ridx, rcnt;
+                Box rb;
+                build_tlas(ms, 0, ms.size(), 1, ridx, rcnt, rb);
+                items.push_back(Item{ITEM_TLAS | flag(), ridx, i0, (uint32_t)grouped.size()});
+            }
+            i0 = i1;
+        }
+        const uint32_t tlas_entries = tlas.empty() ? 0u : tlas_depth + 2u;
+
         // ---- blob layout ------------------------------------------------------
         SceneLayout lay{};
         uint64_t off = 0;
@@ -338,6 +442,8 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         lay.shade_off = (uint32_t)off;  off += (uint64_t)n_triangles * TRI_SHADE_BYTES;
         lay.mat_off = (uint32_t)off;    off += (uint64_t)(n_meshes + n_spheres) * MATERIAL_BYTES;
         lay.sphere_off = (uint32_t)off; off += (uint64_t)n_spheres * SPHERE_BYTES;
+        lay.item_off = (uint32_t)off;   off += (uint64_t)items.size() * ITEM_BYTES;
+        lay.tlas_off = (uint32_t)off;   off += (uint64_t)tlas.size() * WIDE_REC_BYTES;
         if (off == 0) off = 16;
         if (off > 0xfffffff0ull) return fail(h, RT_ERR_CAPACITY, "scene larger than 4 GiB");
         lay.bytes = (uint32_t)off;
@@ -349,14 +455,23 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             memcpy(r, m.world_to_model, 64);
             memcpy(r + 4, m.model_to_world, 64);
             uint32_t flags = 0;
-            if (i > 0 && memcmp(m.world_to_model, meshes[i - 1].world_to_model, 64) == 0) flags |= DMESH_SAME_XFORM;
             if (m.material.flag == RT_MATERIAL_GLASS) flags |= DMESH_GLASS;
             if (deep[i]) flags |= DMESH_DEEP;
             r[8] = make_float4(asf(flags), asf(root_idx[i]), asf(root_count[i]), asf(m.triangle_offset));
             r[9] = make_float4(asf(wide_base[i]), 0.0f, 0.0f, 0.0f);
+            const rt_node& root = nodes[m.node_offset];
+            r[10] = make_float4(root.aabb_min[0], root.aabb_min[1], root.aabb_min[2], 0.0f);
+            r[11] = make_float4(root.aabb_max[0], root.aabb_max[1], root.aabb_max[2], 0.0f);
             memcpy(blob.data() + (lay.mat_off + (size_t)i * MATERIAL_BYTES) / 16, &m.material, MATERIAL_BYTES);
         }
         if (!wide.empty()) memcpy(blob.data() + lay.wide_off / 16, wide.data(), wide.size() * sizeof(WideRec));
+        if (!tlas.empty()) memcpy(blob.data() + lay.tlas_off / 16, tlas.data(), tlas.size() * sizeof(WideRec));
+        for (size_t k = 0; k < items.size(); ++k) {
+            const Item& it = items[k];
+            const bool single = (it.kind & ITEM_TLAS) == 0;
+            blob[lay.item_off / 16 + 2 * k] = make_float4(asf(it.kind), asf(it.a), asf(it.b), asf(single ? wide_base[it.a] : it.n));
+            if (single) blob[lay.item_off / 16 + 2 * k + 1] = blob[(lay.mesh_off + (size_t)it.a * MESH_REC_BYTES) / 16 + 8];
+        }
         // Triangle re-layout (see rt_device.h).  The subtractions and the
         // cross product are wgsl:261-263, evaluated once here in binary32.
         for (uint32_t t = 0; t < n_triangles; ++t) {
@@ -387,14 +502,34 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         int rc;
         if ((rc = upload(h, h->blob, blob.data(), blob.size())) != RT_OK) return rc;
         HIP_TRY(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
+        // The root-box shortcut needs root box == union of the two child boxes, bit for bit
+        // (true for the reference's builder; verified, not assumed, since BVHs may be foreign).
+        bool unions = true;
+        for (uint32_t i = 0; i < n_meshes && unions; ++i) {
+            const rt_node* mn = nodes + meshes[i].node_offset;
+            if (mn[0].count > 0) continue;
+            const rt_node &ca = mn[mn[0].left], &cb = mn[mn[0].right];
+            for (int k = 0; k < 3; ++k) {
+                const float lo_k = ca.aabb_min[k] < cb.aabb_min[k] ? ca.aabb_min[k] : cb.aabb_min[k];
+                const float hi_k = ca.aabb_max[k] > cb.aabb_max[k] ? ca.aabb_max[k] : cb.aabb_max[k];
+                // the root box may also be larger than the union (still conservative)
+                if (!(mn[0].aabb_min[k] <= lo_k && mn[0].aabb_max[k] >= hi_k)) unions = false;
+                // (and the children must be proper boxes, or the interval argument does not hold)
+                if (!(ca.aabb_min[k] <= ca.aabb_max[k] && cb.aabb_min[k] <= cb.aabb_max[k])) unions = false;
+            }
+        }
+        h->roots_are_unions = unions;
         h->lay = lay;
         h->n_meshes = n_meshes;
         h->n_spheres = n_spheres;
         h->n_nodes = n_nodes;
         h->n_triangles = n_triangles;
         h->stack_entries = max_height ? max_height : 1;
+        h->tlas_entries = tlas_entries;
+        h->n_items = (uint32_t)items.size();
         // LDS residency: blob + the four waves' stacks within the per-workgroup budget
-        uint64_t stacks = (uint64_t)h->stack_entries * 128u * sizeof(uint32_t) * WAVES_PER_BLOCK + 8u * 3u * 4u * WAVES_PER_BLOCK;
+        uint64_t stacks = ((uint64_t)h->stack_entries * 128u + (uint64_t)h->tlas_entries * 64u) * sizeof(uint32_t) * WAVES_PER_BLOCK +
+                          8u * 3u * 4u * WAVES_PER_BLOCK;
         h->lds_scene = (uint64_t)lay.bytes + stacks <= LDS_BUDGET_BYTES;
         h->camera = scene->camera;
         h->have_scene = true;
@@ -448,6 +583,11 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "tile_feedback") {
         h->tile_feedback = value ? 1 : 0;
         h->history_valid = false;
+    } else if (n == "tlas") {
+        h->use_tlas = value ? 1 : 0;
+    } else if (n == "cull_roots") {
+        if (value < -1 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "cull_roots must be -1 (auto), 0 or 1");
+        h->cull_roots = value;
     } else if (n == "lds_scene") {
         h->force_global = value ? 0 : 1;
     } else {
@@ -485,6 +625,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.blob = h->blob;
     a.lay = h->lay;
     a.lds_scene = (h->lds_scene && !h->force_global) ? 1u : 0u;
+    a.cull_roots = (h->roots_are_unions && (h->cull_roots == 1 || (h->cull_roots < 0 && h->n_meshes >= 16))) ? 1u : 0u;
     a.textures = h->textures;
     a.srgb_lut = h->srgb_lut;
     a.image = h->image;
@@ -493,6 +634,8 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.n_spheres = h->n_spheres;
     a.n_textures = h->n_textures;
     a.stack_entries = h->stack_entries;
+    a.tlas_entries = h->tlas_entries;
+    a.n_items = h->n_items;
     a.strip_rank = rank;
     a.strip_world = world;
     a.tiles_x = (params->width + 7) / 8;

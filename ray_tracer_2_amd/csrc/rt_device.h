@@ -24,18 +24,34 @@ struct SceneLayout {
     uint32_t shade_off;   // TRI_SHADE_BYTES per triangle
     uint32_t mat_off;     // 96 B rt_material per mesh, then per sphere
     uint32_t sphere_off;  // 16 B (centre, radius) per sphere
+    uint32_t item_off;    // ITEM_BYTES per item of the mesh loop
+    uint32_t tlas_off;    // WIDE_REC_BYTES per node of the top-level trees over mesh root boxes
     uint32_t bytes;       // total, multiple of 16
-    uint32_t _pad;
+    uint32_t _pad[3];
 };
 
-// Mesh record, 10 x 16 B:
+// The mesh loop (wgsl:369) runs over items.  An item is one mesh, or a top-level tree
+// (TLAS) over the root boxes of a run of meshes that share one world_to_model matrix and
+// have internal roots; the order in which meshes are visited is free because ties between
+// equal world distances are broken by mesh index, exactly as the shader's in-order loop with
+// its strict `<` does.  Two 16-byte words per item:
+//   q0 = (kind, a, b, c): kind = ITEM_* flags; b = mesh whose matrices give the local ray when
+//        ITEM_NEW_XFORM is set; single mesh: a = mesh index, c = its wide_base;
+//        TLAS: a = root node index, c = number of meshes below it
+//   q1 = single mesh: a copy of the mesh record's q8 (flags, root_idx, root_count, tri_base), so
+//        that a mesh visit needs no dependent load.
+constexpr uint32_t ITEM_BYTES = 32;
+enum : uint32_t { ITEM_TLAS = 1u, ITEM_NEW_XFORM = 2u };
+constexpr uint32_t TLAS_MIN_MESHES = 8;
+
+// Mesh record, 12 x 16 B:
 //   q0..q3  world_to_model columns   q4..q7  model_to_world columns
 //   q8 = (flags, root_idx, root_count, tri_base)   q9 = (wide_base, 0, 0, 0)
+//   q10 = (root aabb_min, 0)   q11 = (root aabb_max, 0)
 // root_count > 0: the root is a leaf with triangles [root_idx, root_idx+count);
 // root_count == 0: root_idx is the mesh-local index of its wide record.
-constexpr uint32_t MESH_REC_BYTES = 160;
+constexpr uint32_t MESH_REC_BYTES = 192;
 enum : uint32_t {
-    DMESH_SAME_XFORM = 1u,  // world_to_model bit-identical to the previous mesh's
     DMESH_GLASS = 2u,       // material.flag == GLASS  => no backface culling (wgsl:375)
     DMESH_DEEP = 4u,        // BVH height >= 32: the shader's 32-entry stack can overflow; traverse it
                             // with the shader's literal push/pop and index clamping (naga Restrict)
@@ -87,14 +103,16 @@ struct RenderArgs {
     uint32_t* work_counter;  // persistent kernel: next 8x8 tile to hand out (zeroed per launch)
     const uint32_t* tile_order;  // optional: tiles sorted by last frame's cost, heaviest first
     uint32_t* tile_cost;         // optional: rays per tile of this frame (feeds the next frame's order)
-    uint32_t n_meshes, n_spheres, n_textures;
-    uint32_t stack_entries;  // per-lane BVH stack depth
+    uint32_t n_meshes, n_spheres, n_textures, n_items;
+    uint32_t stack_entries;  // per-lane BVH stack depth (2 dwords per entry)
+    uint32_t tlas_entries;   // per-lane TLAS stack depth (1 dword per entry), 0 without a TLAS
     uint32_t strip_rank, strip_world;
     uint32_t tiles_x, tiles_y;  // 8x8 tiles of the (local) image
     uint32_t count_tests;       // 1 => accumulate node/triangle test counters
     uint32_t kernel_variant;    // 0 = persistent waves + lane refill, 1 = one wave per tile
     uint32_t persistent_blocks; // grid size of the persistent kernel
     uint32_t lds_scene;         // 1 => the blob is staged into LDS
+    uint32_t cull_roots;        // 1 => skip a mesh with an internal root when the ray misses the root box
 };
 
 }  // namespace rtd

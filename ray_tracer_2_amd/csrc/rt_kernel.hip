@@ -366,9 +366,11 @@ struct Hit {
 // wgsl:353-396 (+ ray_sphere :223-256).  Per-object outputs that only the
 // overall winner needs (normals, uv) are computed once after the loops from
 // the same inputs, which yields the same bits.
-template <bool LDS, bool STATS>
+template <bool LDS, bool STATS, bool TLAS>
 DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int& node_tests,
                         int& tri_tests) {
+    // this lane's TLAS stack column sits behind the wave's BVH stack columns
+    uint32_t* tstack = stack + (a.stack_entries ? a.stack_entries : 1u) * 128u;
     float closest = INF;
     int object = 0;  // >= 0 mesh index, < 0 sphere -(index) - 1
     bool any = false;
@@ -399,28 +401,20 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             }
         }
     }
-    // meshes
+    // meshes (wgsl:369-393), as items: single meshes and top-level trees over mesh root boxes
     f3 lo{0, 0, 0}, ld{0, 0, 0}, inv{0, 0, 0};
+    bool cull_ok = false;
     MeshBest win{};  // winner's triangle data
     f3 win_point{0, 0, 0};
-    for (uint32_t i = 0; i < a.n_meshes; ++i) {
+    // closest-hit update of wgsl:383-391; equal distances go to the lower mesh index, which is
+    // what the shader's in-order loop with its strict `<` yields
+    auto visit_mesh = [&](uint32_t i, float4 hdr, uint32_t wide_base) {
         const uint32_t mo = a.lay.mesh_off + i * MESH_REC_BYTES;
-        const float4 hdr = ld4<LDS>(a, mo + 128);
         const uint32_t flags = fbits(hdr.x);
-        if ((flags & DMESH_SAME_XFORM) == 0) {
-            DIAG(3);
-            // identical matrix => identical local ray: reuse (same bits)
-            const float4 c0 = ld4<LDS>(a, mo), c1 = ld4<LDS>(a, mo + 16), c2 = ld4<LDS>(a, mo + 32),
-                         c3 = ld4<LDS>(a, mo + 48);
-            lo = mat_cols_xyz(c0, c1, c2, c3, ro, 1.0f);
-            ld = normalize3(mat_cols_xyz(c0, c1, c2, c3, rd, 0.0f));
-            inv = f3{1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z};
-        }
         MeshBest b;
         b.t = INF;
         b.tri = 0xffffffffu;
         b.u = b.v = b.w = b.det = 0.0f;
-        const uint32_t wide_base = fbits(ld4<LDS>(a, mo + 144).x);
         traverse_mesh<LDS, STATS>(a, fbits(hdr.y), fbits(hdr.z), fbits(hdr.w), wide_base,
                                   (flags & DMESH_GLASS) == 0, (flags & DMESH_DEEP) != 0, lo, ld, inv, stack, b,
                                   node_tests, tri_tests);
@@ -432,12 +426,82 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             f3 whp = mat_cols_xyz(c0, c1, c2, c3, lhp, 1.0f);
             f3 dv = ro - whp;
             float wdst = rtm::sqrt_(dot3(dv, dv));
-            if (wdst < closest) {
+            if (wdst < closest || (wdst == closest && any && object >= 0 && (int)i < object)) {
                 closest = wdst;
                 any = true;
                 object = (int)i;
                 win = b;
                 win_point = whp;
+            }
+        }
+    };
+    for (uint32_t it = 0; it < a.n_items; ++it) {
+        const float4 item = ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES);
+        // item words are the same in every lane: keep them scalar
+        const uint32_t kind = __builtin_amdgcn_readfirstlane(fbits(item.x));
+        const uint32_t ia = __builtin_amdgcn_readfirstlane(fbits(item.y));
+        if (kind & ITEM_NEW_XFORM) {
+            DIAG(3);
+            // meshes with bit-identical world_to_model share the local ray (same inputs, same bits)
+            const uint32_t xo = a.lay.mesh_off + __builtin_amdgcn_readfirstlane(fbits(item.z)) * MESH_REC_BYTES;
+            const float4 c0 = ld4<LDS>(a, xo), c1 = ld4<LDS>(a, xo + 16), c2 = ld4<LDS>(a, xo + 32),
+                         c3 = ld4<LDS>(a, xo + 48);
+            lo = mat_cols_xyz(c0, c1, c2, c3, ro, 1.0f);
+            ld = normalize3(mat_cols_xyz(c0, c1, c2, c3, rd, 0.0f));
+            inv = f3{1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z};
+            // the root-box arguments below are only proven for finite slab arithmetic
+            if constexpr (TLAS)
+                cull_ok = rtm::abs_(inv.x) < INF && rtm::abs_(inv.y) < INF && rtm::abs_(inv.z) < INF &&
+                          rtm::abs_(lo.x) < INF && rtm::abs_(lo.y) < INF && rtm::abs_(lo.z) < INF;
+        }
+        if (!TLAS || (kind & ITEM_TLAS) == 0u) {
+            const uint32_t mo = a.lay.mesh_off + ia * MESH_REC_BYTES;
+            const float4 hdr = ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16);
+            if (TLAS && a.cull_roots && fbits(hdr.z) == 0u) {
+                // Mesh-level culling that cannot change the result.  The shader never
+                // tests the root box, only its two children (wgsl:316-321) -- but the root box
+                // contains the child boxes and IEEE subtraction/multiplication/min/max are
+                // monotone, so with finite operands each child's slab interval lies inside the
+                // root's: a ray that misses the root box fails both child tests and the mesh
+                // contributes nothing.  (0 * inf = NaN would break monotonicity: cull_ok.)
+                const float4 rmin = ld4<LDS>(a, mo + 160), rmax = ld4<LDS>(a, mo + 176);
+                const bool may_hit = !cull_ok || aabb_dist(lo, inv, rmin, rmax, INF) < INF;
+                if (!may_hit) {
+                    if (STATS) node_tests += 2;  // the two child tests the shader would have made (wgsl:322)
+                    continue;
+                }
+            }
+            visit_mesh(ia, hdr, __builtin_amdgcn_readfirstlane(fbits(item.w)));
+        } else if constexpr (TLAS) {
+            // Top-level tree over the root boxes of fbits(item.w) meshes (all with internal roots,
+            // one shared local space).  Every tree box contains the root boxes below it, so by the
+            // same monotonicity argument a ray that misses a tree box misses every mesh below it.
+            if (STATS) node_tests += 2 * (int)fbits(item.w);  // each mesh's two root-level tests (wgsl:322)
+            uint32_t tsp = 1;
+            tstack[0] = ia;  // internal tree node
+            while (tsp > 0) {
+                --tsp;
+                const uint32_t e = tstack[tsp * 64];
+                if (e & 0x80000000u) {
+                    const uint32_t mi = e & 0x7fffffffu;
+                    if (STATS) node_tests -= 2;  // counted above; traverse_mesh counts them again
+                    const uint32_t mo = a.lay.mesh_off + mi * MESH_REC_BYTES;
+                    visit_mesh(mi, ld4<LDS>(a, mo + 128), fbits(ld4<LDS>(a, mo + 144).x));
+                } else {
+                    const uint32_t wo = a.lay.tlas_off + e * WIDE_REC_BYTES;
+                    const float4 q0 = ld4<LDS>(a, wo), q1 = ld4<LDS>(a, wo + 16), q2 = ld4<LDS>(a, wo + 32),
+                                 q3 = ld4<LDS>(a, wo + 48);
+                    const bool hit_a = !cull_ok || aabb_dist(lo, inv, q0, q1, INF) < INF;
+                    const bool hit_b = !cull_ok || aabb_dist(lo, inv, q2, q3, INF) < INF;
+                    if (hit_b) {
+                        tstack[tsp * 64] = fbits(q2.w) | (fbits(q3.w) ? 0x80000000u : 0u);
+                        ++tsp;
+                    }
+                    if (hit_a) {
+                        tstack[tsp * 64] = fbits(q0.w) | (fbits(q1.w) ? 0x80000000u : 0u);
+                        ++tsp;
+                    }
+                }
             }
         }
     }
@@ -574,7 +638,7 @@ DEV uint32_t* block_prologue(const RenderArgs& a) {
         stack_base = n16;
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t per_wave = (a.stack_entries ? a.stack_entries : 1u) * 128u;  // dwords
+    const uint32_t per_wave = (a.stack_entries ? a.stack_entries : 1u) * 128u + a.tlas_entries * 64u;  // dwords
     return reinterpret_cast<uint32_t*>(lds_mem + stack_base) + wave * per_wave + lane;
 }
 
@@ -582,7 +646,7 @@ DEV uint32_t* block_prologue(const RenderArgs& a) {
 template <bool LDS>
 DEV uint32_t* cost_table_of_wave(const RenderArgs& a) {
     const uint32_t stack_base = LDS ? (a.lay.bytes >> 4) : 0u;  // float4 units
-    const uint32_t per_wave = (a.stack_entries ? a.stack_entries : 1u) * 128u;
+    const uint32_t per_wave = (a.stack_entries ? a.stack_entries : 1u) * 128u + a.tlas_entries * 64u;
     return reinterpret_cast<uint32_t*>(lds_mem + stack_base) + WAVES_PER_BLOCK * per_wave +
            (threadIdx.x >> 6) * (8u * 3u);
 }
@@ -650,7 +714,7 @@ DEV void pixel_begin(const RenderArgs& a, const CameraConsts& c, PixelState& s, 
 
 // One iteration of the per-lane state machine: (start the next sample) + one
 // path segment + its shading.  Returns true when the pixel's last sample ended.
-template <bool LDS, bool STATS>
+template <bool LDS, bool STATS, bool TLAS>
 DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, uint32_t* stack,
                    uint32_t& n_segments, int& node_tests, int& tri_tests) {
     const int32_t nb = a.params.number_of_bounces;
@@ -672,7 +736,7 @@ DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, ui
     }
     bool end_path = true;
     if (s.seg <= nb) {
-        Hit hit = intersect_scene<LDS, STATS>(a, s.ro, s.rd, stack, node_tests, tri_tests);
+        Hit hit = intersect_scene<LDS, STATS, TLAS>(a, s.ro, s.rd, stack, node_tests, tri_tests);
         n_segments += 1;
         if ((s.meta & 0xffffu) != 0xffffu) s.meta += 1;
         if (!hit.hit) {
@@ -805,7 +869,7 @@ DEV void flush_counters(const RenderArgs& a, uint32_t n_segments, int node_tests
 
 // Variant 1: one wave per 8x8 tile (the reference's dispatch shape), four
 // tiles per workgroup.
-template <bool LDS, bool STATS>
+template <bool LDS, bool STATS, bool TLAS>
 __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_kernel(const RenderArgs a) {
     uint32_t* stack = block_prologue<LDS>(a);
     const CameraConsts cam = camera_consts(a);
@@ -820,7 +884,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     uint32_t n_segments = 0;
     int node_tests = 0, tri_tests = 0;
     while (active) {
-        if (path_step<LDS, STATS>(a, cam, s, stack, n_segments, node_tests, tri_tests)) active = false;
+        if (path_step<LDS, STATS, TLAS>(a, cam, s, stack, n_segments, node_tests, tri_tests)) active = false;
     }
     if (valid) pixel_finish(a, s);
     if (a.tile_cost && tile_ok) {  // one store per wave: the tile's rays
@@ -837,7 +901,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
 // wave's current tile, so the wave stays full until the frame runs out.  The
 // per-pixel RNG stream depends only on the pixel's coordinates, so the image
 // does not depend on which lane rendered which pixel.
-template <bool LDS, bool STATS>
+template <bool LDS, bool STATS, bool TLAS>
 __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persistent_kernel(const RenderArgs a) {
     uint32_t* stack = block_prologue<LDS>(a);
     const uint32_t lane = threadIdx.x & 63u;
@@ -903,7 +967,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
             continue;
         }
         if (active) {
-            if (path_step<LDS, STATS>(a, cam, s, stack, n_segments, node_tests, tri_tests)) {
+            if (path_step<LDS, STATS, TLAS>(a, cam, s, stack, n_segments, node_tests, tri_tests)) {
                 DIAG(16);
                 pixel_finish(a, s);
                 if (a.tile_cost) tile_cost_add(a, cost_tbl, s);
@@ -934,7 +998,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rt_debug_kernel(const RenderArg
     const f3 focus_point = mat_xyz(c2w, local_focus, 1.0f);
     f3 rd = normalize3(focus_point - cam_origin);
     int s0 = 0, s1 = 0;
-    Hit hit = intersect_scene<LDS, true>(a, cam_origin, rd, stack, s0, s1);
+    Hit hit = intersect_scene<LDS, true, true>(a, cam_origin, rd, stack, s0, s1);
     const float scale = (float)a.params.debug_scale;
     f4 out{1.0f, 0.0f, 1.0f, 1.0f};
     switch (a.params.debug_flag) {
@@ -1071,7 +1135,8 @@ hipError_t diag_read(unsigned long long* out, bool reset) {
 
 // Launchers (called from rt_api.hip)
 size_t render_lds_bytes(const RenderArgs& a) {
-    size_t stacks = (size_t)(a.stack_entries ? a.stack_entries : 1u) * 128u * sizeof(uint32_t) * WAVES_PER_BLOCK;
+    size_t stacks = ((size_t)(a.stack_entries ? a.stack_entries : 1u) * 128u + (size_t)a.tlas_entries * 64u) *
+                    sizeof(uint32_t) * WAVES_PER_BLOCK;
     size_t cost_tables = 8u * 3u * sizeof(uint32_t) * WAVES_PER_BLOCK;
     return stacks + cost_tables + (a.lds_scene ? a.lay.bytes : 0u);
 }
@@ -1084,19 +1149,19 @@ static void launch_k(K kernel, uint32_t blocks, size_t lds, hipStream_t stream, 
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), lds, stream, a);
 }
 
-template <bool LDS>
+template <bool LDS, bool TLAS>
 static void launch_variant(const RenderArgs& a, uint32_t ntiles, size_t lds, hipStream_t stream) {
     const uint32_t tile_blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (a.params.debug_flag != 0) {
         launch_k(rt_debug_kernel<LDS>, tile_blocks, lds, stream, a);
     } else if (a.kernel_variant == 1) {
-        if (a.count_tests) launch_k(rt_render_tiles_kernel<LDS, true>, tile_blocks, lds, stream, a);
-        else launch_k(rt_render_tiles_kernel<LDS, false>, tile_blocks, lds, stream, a);
+        if (a.count_tests) launch_k(rt_render_tiles_kernel<LDS, true, TLAS>, tile_blocks, lds, stream, a);
+        else launch_k(rt_render_tiles_kernel<LDS, false, TLAS>, tile_blocks, lds, stream, a);
     } else {
         uint32_t blocks = a.persistent_blocks < tile_blocks ? a.persistent_blocks : tile_blocks;
         if (blocks == 0) blocks = 1;
-        if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true>, blocks, lds, stream, a);
-        else launch_k(rt_render_persistent_kernel<LDS, false>, blocks, lds, stream, a);
+        if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS>, blocks, lds, stream, a);
+        else launch_k(rt_render_persistent_kernel<LDS, false, TLAS>, blocks, lds, stream, a);
     }
 }
 
@@ -1104,8 +1169,16 @@ hipError_t launch_render(const RenderArgs& a, hipStream_t stream) {
     uint32_t ntiles = a.tiles_x * a.tiles_y;
     if (ntiles == 0) return hipSuccess;
     size_t lds = render_lds_bytes(a);
-    if (a.lds_scene) launch_variant<true>(a, ntiles, lds, stream);
-    else launch_variant<false>(a, ntiles, lds, stream);
+    // the many-mesh code (top-level trees, root-box culling) is only compiled into the kernels
+    // that need it (register budget)
+    const bool tlas = a.tlas_entries != 0 || a.cull_roots != 0;
+    if (a.lds_scene) {
+        if (tlas) launch_variant<true, true>(a, ntiles, lds, stream);
+        else launch_variant<true, false>(a, ntiles, lds, stream);
+    } else {
+        if (tlas) launch_variant<false, true>(a, ntiles, lds, stream);
+        else launch_variant<false, false>(a, ntiles, lds, stream);
+    }
     return hipGetLastError();
 }
 

@@ -61,3 +61,71 @@ def cornell_dragon(cornell_raw, dragon_raw, subdivide=3):
         sc.add_mesh_from_data(v, idx, xform=t, mat=m)
     sc.build()
     return sc
+
+
+def _box_mesh(lo, hi):
+    """12 triangles, outward normals, per-face uv in [0, 1]; vertices8 + indices."""
+    lo, hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+    faces = [  # (origin, du, dv, normal)
+        ((lo[0], lo[1], hi[2]), (hi[0] - lo[0], 0, 0), (0, hi[1] - lo[1], 0), (0, 0, 1)),
+        ((hi[0], lo[1], lo[2]), (lo[0] - hi[0], 0, 0), (0, hi[1] - lo[1], 0), (0, 0, -1)),
+        ((hi[0], lo[1], hi[2]), (0, 0, lo[2] - hi[2]), (0, hi[1] - lo[1], 0), (1, 0, 0)),
+        ((lo[0], lo[1], lo[2]), (0, 0, hi[2] - lo[2]), (0, hi[1] - lo[1], 0), (-1, 0, 0)),
+        ((lo[0], hi[1], hi[2]), (hi[0] - lo[0], 0, 0), (0, 0, lo[2] - hi[2]), (0, 1, 0)),
+        ((lo[0], lo[1], lo[2]), (hi[0] - lo[0], 0, 0), (0, 0, hi[2] - lo[2]), (0, -1, 0)),
+    ]
+    v, idx = [], []
+    for o, du, dv, n in faces:
+        o, du, dv = np.float32(o), np.float32(du), np.float32(dv)
+        base = len(v)
+        for (a, b) in ((0, 0), (1, 0), (1, 1), (0, 1)):
+            p = o + du * a + dv * b
+            v.append([p[0], p[1], p[2], n[0], n[1], n[2], 2.0 * a, 2.0 * b])   # uv beyond 1: repeat addressing
+        idx += [base, base + 1, base + 2, base, base + 2, base + 3]
+    return np.array(v, np.float32), np.array(idx, np.uint32)
+
+
+def sponza_standin(n_meshes=200, seed=11):
+    """BASELINE config 4 stand-in (sponza.obj and 4 of its textures are missing from the checkout):
+    a many-mesh textured atrium with the structure of Scene::sponza (scene.rs:864-910) -- one OBJ's
+    worth of groups sharing a single transform of scale 0.05, textured materials, plus the emissive
+    quad and the emissive sphere -- built procedurally: a floor, a ceiling band, and rows of columns
+    and blocks (12 triangles each), `n_meshes` meshes in all, 8 procedural textures."""
+    rng = np.random.RandomState(seed)
+    sc = Scene()
+    sc.set_camera((0, 4, 0), (0, 4, 1))   # scene.rs:867-870
+    tex_ids = []
+    for t in range(8):
+        yy, xx = np.mgrid[0:64, 0:64]
+        base = rng.randint(40, 215, 3)
+        pat = ((xx // (4 + t)) + (yy // (3 + t))) % 2
+        img = np.zeros((64, 64, 4), np.uint8)
+        for c in range(3):
+            img[..., c] = np.clip(base[c] + pat * 40 - 20 + rng.randint(-10, 10, (64, 64)), 0, 255)
+        img[..., 3] = 255
+        tex_ids.append(sc.add_texture_rgba8(img))
+    xf = transform(scale=(0.05, 0.05, 0.05))   # scene.rs:873-877
+    def textured(i):
+        return material(color=(0.7, 0.7, 0.7, 1), specular_color=(1, 1, 1, 1), smoothness=0.3, specular=0.04,
+                        flag=A.MATERIAL_TEXTURE, diffuse_index=tex_ids[i % len(tex_ids)])
+    boxes = [((-300, -2, -150), (300, 0, 150)), ((-300, 250, -150), (300, 252, -60)), ((-300, 250, 60), (300, 252, 150))]
+    k = 0
+    while len(boxes) < n_meshes:
+        row = k % 4
+        x = -280 + (k // 4) * 23.0
+        zc = (-120, -45, 45, 120)[row]
+        w, d, hgt = rng.uniform(6, 10), rng.uniform(6, 10), rng.uniform(60, 240)
+        boxes.append(((x - w, 0, zc - d), (x + w, hgt, zc + d)))
+        k += 1
+    for i, (lo, hi) in enumerate(boxes[:n_meshes]):
+        v, idx = _box_mesh(lo, hi)
+        sc.add_mesh_from_data(v, idx, xform=xf, mat=textured(i))
+    h = float(np.sin(np.pi / 4)), float(np.cos(np.pi / 4))
+    quad = np.array([[-1, -1, 0, 0, 0, 1, 0, 0], [1, -1, 0, 0, 0, 1, 1, 0], [1, 1, 0, 0, 0, 1, 1, 1], [-1, 1, 0, 0, 0, 1, 0, 1]], np.float32)
+    sc.add_mesh_from_data(quad, [0, 1, 2, 0, 2, 3], xform=transform(pos=(-15, 60, 0), rot=(h[0], 0, 0, h[1]), scale=(40, 20, 1)),
+                          mat=material(color=(0.7, 0.7, 0.7, 1), emission_color=(1, 1, 1, 1), specular_color=(1, 1, 1, 1),
+                                       emission_strength=4.0, smoothness=1.0))   # scene.rs:884-892
+    sc.add_sphere((5, 2, 0), 2.0, material(color=(1, 1, 1, 1), emission_color=(1, 1, 1, 1), specular_color=(1, 1, 1, 1),
+                                          emission_strength=10.0, smoothness=0.0, specular=0.0))   # scene.rs:894-908
+    sc.build()
+    return sc

@@ -362,3 +362,30 @@ def test_config5_geometry_standin(rt, oracle, tracer):
     oracle.render(rt.make_params(3840, 2160, 8, 1, skybox=1, frames=0), a, image=ref4k, rows=rows)
     assert np.array_equal(bits(img[rows]), bits(ref4k[rows]))
     big.close()
+
+
+def test_config4_sponza_standin(rt, oracle, tracer):
+    """BASELINE config 4 stand-in: many textured meshes under one transform (the no-TLAS mesh loop,
+    wgsl:369), an emissive quad with its own transform, an emissive sphere; bit-exact."""
+    from ray_tracer_2_amd import scenes
+    a = rt.SceneArrays.from_scene(scenes.sponza_standin(200))
+    assert a.meshes.shape[0] == 201 and len(a.textures) == 8
+    p = rt.make_params(192, 108, 4, 4, skybox=1, frames=0)
+    # neither the top-level tree over mesh root boxes nor root-box culling may change a bit,
+    # nor the node/triangle test counters the debug views show
+    for variant, tlas, cull in ((0, 1, 1), (1, 1, 1), (0, 0, 1), (0, 0, 0)):
+        tracer.set_option("kernel_variant", variant)
+        tracer.set_option("tlas", tlas)
+        tracer.set_option("cull_roots", cull)
+        tracer.set_counters(True)
+        gpu, ref, s, st = render_both(rt, oracle, tracer, a, p)
+        tracer.set_counters(False)
+        assert same(gpu, ref), (variant, tlas, cull)
+        assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests)
+    tracer.set_option("kernel_variant", -1)
+    tracer.set_option("tlas", 1)
+    tracer.set_option("cull_roots", -1)
+    for dbg in (1, 3, 5):
+        pd = rt.make_params(192, 108, 4, 1, debug_flag=dbg, debug_scale=500)
+        gpu, ref, _, _ = render_both(rt, oracle, tracer, a, pd)
+        assert same(gpu, ref), dbg

@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ray_tracer_2_amd as rt  # noqa: E402
 
-ALIAS = {"variant": "kernel_variant", "blocks": "persistent_blocks", "lds": "lds_scene", "fb": "tile_feedback"}
-DEFAULTS = {"kernel_variant": -1, "lds_scene": 1, "tile_feedback": 1}
+ALIAS = {"variant": "kernel_variant", "blocks": "persistent_blocks", "lds": "lds_scene", "fb": "tile_feedback", "cull": "cull_roots"}
+DEFAULTS = {"kernel_variant": -1, "lds_scene": 1, "tile_feedback": 1, "cull_roots": -1}
 
 
 def main():
@@ -36,7 +36,10 @@ def main():
     for r in range(rounds + 1):
         for name, opts in configs:
             for k, v in DEFAULTS.items():
-                tr.set_option(k, v)
+                try:
+                    tr.set_option(k, v)
+                except rt.RtError:
+                    pass  # older experimental library without this option
             for k, v in opts.items():
                 tr.set_option(k, v)
             tr.reset_timing()

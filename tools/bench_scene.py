@@ -15,8 +15,11 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     g = os.path.join(ROOT, "tests", "golden")
-    sc = scenes.cornell_dragon(scenes.load_raw_meshes(os.path.join(g, "cornell_raw.npz")),
-                               scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")), subdivide=n)
+    if n == 0:   # config 4 stand-in: many textured meshes
+        sc = scenes.sponza_standin(200)
+    else:
+        sc = scenes.cornell_dragon(scenes.load_raw_meshes(os.path.join(g, "cornell_raw.npz")),
+                                   scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")), subdivide=n)
     arrays = rt.SceneArrays.from_scene(sc)
     W, H = 1920, 1080
     tr = rt.RayTracer(0, W, H)
