@@ -28,6 +28,9 @@ hipError_t launch_assemble(const float4* gathered, float4* image, uint32_t width
 #if defined(RT_DIAG)
 hipError_t diag_read(unsigned long long* out, bool reset);
 #endif
+#if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
+hipError_t diag_wave_times(unsigned long long* out);
+#endif
 }  // namespace rtd
 
 using namespace rtd;
@@ -73,7 +76,8 @@ struct rt_handle {
     DTexture* textures = nullptr;
     std::vector<uint8_t*> texture_data;
     uint32_t n_meshes = 0, n_spheres = 0, n_textures = 0, n_nodes = 0, n_triangles = 0;
-    uint32_t stack_entries = 1, tlas_entries = 0, n_items = 0;
+    uint32_t stack_entries = 1, tlas_entries = 1, n_items = 0;
+    bool has_tlas = false;
     int use_tlas = 1;  // option "tlas": 0 = every mesh is a single item (takes effect at the next upload)
     rt_camera_uniform camera{};
     int count_tests = 0;
@@ -431,7 +435,10 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             }
             i0 = i1;
         }
-        const uint32_t tlas_entries = tlas.empty() ? 0u : tlas_depth + 2u;
+        // (one entry is always there: the many-mesh kernels, which the debug views use too,
+        // run single meshes through the same stack)
+        const uint32_t tlas_entries = tlas.empty() ? 1u : tlas_depth + 2u;
+        const bool has_tlas = !tlas.empty();
 
         // ---- blob layout ------------------------------------------------------
         SceneLayout lay{};
@@ -526,6 +533,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->n_triangles = n_triangles;
         h->stack_entries = max_height ? max_height : 1;
         h->tlas_entries = tlas_entries;
+        h->has_tlas = has_tlas;
         h->n_items = (uint32_t)items.size();
         // LDS residency: blob + the four waves' stacks within the per-workgroup budget
         uint64_t stacks = ((uint64_t)h->stack_entries * 128u + (uint64_t)h->tlas_entries * 64u) * sizeof(uint32_t) * WAVES_PER_BLOCK +
@@ -626,6 +634,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.lay = h->lay;
     a.lds_scene = (h->lds_scene && !h->force_global) ? 1u : 0u;
     a.cull_roots = (h->roots_are_unions && (h->cull_roots == 1 || (h->cull_roots < 0 && h->n_meshes >= 16))) ? 1u : 0u;
+    a.many_mesh = (h->has_tlas || a.cull_roots) ? 1u : 0u;
     a.textures = h->textures;
     a.srgb_lut = h->srgb_lut;
     a.image = h->image;
@@ -873,6 +882,15 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels) {
     return RT_OK;
 }
 
+#if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
+int rt_diag_wave_times(rt_handle* h, unsigned long long* out) {
+    if (!h || !out) return RT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, rtd::diag_wave_times(out));
+    return RT_OK;
+}
+#endif
 #if defined(RT_DIAG)
 int rt_diag_read(rt_handle* h, unsigned long long* out64, int reset) {
     if (!h || !out64) return RT_ERR_INVALID_ARGUMENT;

@@ -105,7 +105,8 @@ struct RenderArgs {
     uint32_t* tile_cost;         // optional: rays per tile of this frame (feeds the next frame's order)
     uint32_t n_meshes, n_spheres, n_textures, n_items;
     uint32_t stack_entries;  // per-lane BVH stack depth (2 dwords per entry)
-    uint32_t tlas_entries;   // per-lane TLAS stack depth (1 dword per entry), 0 without a TLAS
+    uint32_t tlas_entries;   // per-lane TLAS stack depth (1 dword per entry), >= 1
+    uint32_t many_mesh;      // 1 => use the kernels with top-level trees / root-box culling compiled in
     uint32_t strip_rank, strip_world;
     uint32_t tiles_x, tiles_y;  // 8x8 tiles of the (local) image
     uint32_t count_tests;       // 1 => accumulate node/triangle test counters

@@ -48,6 +48,9 @@ namespace {
 
 // Diagnostic build only (-DRT_DIAG=1, tools/diag.py): per-section wave visits
 // and active-lane sums, to price divergence.  Compiled out of the product.
+#if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
+__device__ unsigned long long g_wave_times[2 * 8192];  // (start, end) s_memrealtime per persistent wave
+#endif
 #if defined(RT_DIAG)
 __device__ unsigned long long g_diag[64];
 #define DIAG(id)                                                                  \
@@ -454,39 +457,53 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                 cull_ok = rtm::abs_(inv.x) < INF && rtm::abs_(inv.y) < INF && rtm::abs_(inv.z) < INF &&
                           rtm::abs_(lo.x) < INF && rtm::abs_(lo.y) < INF && rtm::abs_(lo.z) < INF;
         }
-        if (!TLAS || (kind & ITEM_TLAS) == 0u) {
-            const uint32_t mo = a.lay.mesh_off + ia * MESH_REC_BYTES;
-            const float4 hdr = ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16);
-            if (TLAS && a.cull_roots && fbits(hdr.z) == 0u) {
-                // Mesh-level culling that cannot change the result.  The shader never
-                // tests the root box, only its two children (wgsl:316-321) -- but the root box
-                // contains the child boxes and IEEE subtraction/multiplication/min/max are
-                // monotone, so with finite operands each child's slab interval lies inside the
-                // root's: a ray that misses the root box fails both child tests and the mesh
-                // contributes nothing.  (0 * inf = NaN would break monotonicity: cull_ok.)
-                const float4 rmin = ld4<LDS>(a, mo + 160), rmax = ld4<LDS>(a, mo + 176);
-                const bool may_hit = !cull_ok || aabb_dist(lo, inv, rmin, rmax, INF) < INF;
-                if (!may_hit) {
-                    if (STATS) node_tests += 2;  // the two child tests the shader would have made (wgsl:322)
-                    continue;
+        if constexpr (!TLAS) {
+            visit_mesh(ia, ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16),
+                       __builtin_amdgcn_readfirstlane(fbits(item.w)));
+        } else {
+            // Many-mesh kernels: one traversal loop serves single meshes (a one-entry stack)
+            // and top-level trees, so the mesh visit is instantiated once.
+            uint32_t tsp = 0;
+            if ((kind & ITEM_TLAS) == 0u) {
+                bool may_hit = true;
+                const uint32_t root_count = fbits(ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16).z);
+                if (a.cull_roots && root_count == 0u) {
+                    // Mesh-level culling that cannot change the result.  The shader
+                    // never tests the root box, only its two children (wgsl:316-321) -- but the
+                    // root box contains the child boxes and IEEE subtraction / multiplication /
+                    // min / max are monotone, so with finite operands each child's slab interval
+                    // lies inside the root's: a ray that misses the root box fails both child
+                    // tests and the mesh contributes nothing.  (0 * inf = NaN would break
+                    // monotonicity: cull_ok.)
+                    const uint32_t mo = a.lay.mesh_off + ia * MESH_REC_BYTES;
+                    const float4 rmin = ld4<LDS>(a, mo + 160), rmax = ld4<LDS>(a, mo + 176);
+                    may_hit = !cull_ok || aabb_dist(lo, inv, rmin, rmax, INF) < INF;
                 }
+                // counter bookkeeping: the leaf branch below subtracts the two root-level tests that
+                // traverse_mesh counts again; a culled mesh (always an internal root) keeps them
+                if (STATS) node_tests += 2;
+                if (may_hit) {
+                    tstack[0] = ia | 0x80000000u;
+                    tsp = 1;
+                }
+            } else {
+                // Top-level tree over the root boxes of fbits(item.w) meshes (all with internal
+                // roots, one shared local space).  Every tree box contains the root boxes below
+                // it, so by the same monotonicity argument a ray that misses a tree box misses
+                // every mesh below it.  Each mesh still counts its two root-level tests (wgsl:322).
+                if (STATS) node_tests += 2 * (int)fbits(item.w);
+                tstack[0] = ia;  // internal tree node
+                tsp = 1;
             }
-            visit_mesh(ia, hdr, __builtin_amdgcn_readfirstlane(fbits(item.w)));
-        } else if constexpr (TLAS) {
-            // Top-level tree over the root boxes of fbits(item.w) meshes (all with internal roots,
-            // one shared local space).  Every tree box contains the root boxes below it, so by the
-            // same monotonicity argument a ray that misses a tree box misses every mesh below it.
-            if (STATS) node_tests += 2 * (int)fbits(item.w);  // each mesh's two root-level tests (wgsl:322)
-            uint32_t tsp = 1;
-            tstack[0] = ia;  // internal tree node
             while (tsp > 0) {
                 --tsp;
                 const uint32_t e = tstack[tsp * 64];
                 if (e & 0x80000000u) {
                     const uint32_t mi = e & 0x7fffffffu;
-                    if (STATS) node_tests -= 2;  // counted above; traverse_mesh counts them again
                     const uint32_t mo = a.lay.mesh_off + mi * MESH_REC_BYTES;
-                    visit_mesh(mi, ld4<LDS>(a, mo + 128), fbits(ld4<LDS>(a, mo + 144).x));
+                    const float4 hdr = ld4<LDS>(a, mo + 128);
+                    if (STATS) node_tests -= 2;  // counted above; traverse_mesh counts them again
+                    visit_mesh(mi, hdr, fbits(ld4<LDS>(a, mo + 144).x));
                 } else {
                     const uint32_t wo = a.lay.tlas_off + e * WIDE_REC_BYTES;
                     const float4 q0 = ld4<LDS>(a, wo), q1 = ld4<LDS>(a, wo + 16), q2 = ld4<LDS>(a, wo + 32),
@@ -903,6 +920,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
 // does not depend on which lane rendered which pixel.
 template <bool LDS, bool STATS, bool TLAS>
 __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persistent_kernel(const RenderArgs a) {
+#if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
+    const unsigned long long t_wave_start = __builtin_amdgcn_s_memrealtime();
+#endif
     uint32_t* stack = block_prologue<LDS>(a);
     const uint32_t lane = threadIdx.x & 63u;
     const CameraConsts cam = camera_consts(a);
@@ -976,6 +996,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         }
     }
     flush_counters<STATS>(a, n_segments, node_tests, tri_tests);
+#if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
+    if (lane == 0) {
+        const uint32_t w = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+        if (w < 8192) {
+            g_wave_times[2 * w] = t_wave_start;
+            g_wave_times[2 * w + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1121,6 +1150,11 @@ hipError_t launch_tile_order(const uint32_t* cost, uint32_t n_tiles, uint32_t ma
     return hipGetLastError();
 }
 
+#if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
+hipError_t diag_wave_times(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(unsigned long long) * 2 * 8192);
+}
+#endif
 #if defined(RT_DIAG)
 hipError_t diag_read(unsigned long long* out, bool reset) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 64);
@@ -1171,7 +1205,7 @@ hipError_t launch_render(const RenderArgs& a, hipStream_t stream) {
     size_t lds = render_lds_bytes(a);
     // the many-mesh code (top-level trees, root-box culling) is only compiled into the kernels
     // that need it (register budget)
-    const bool tlas = a.tlas_entries != 0 || a.cull_roots != 0;
+    const bool tlas = a.many_mesh != 0;
     if (a.lds_scene) {
         if (tlas) launch_variant<true, true>(a, ntiles, lds, stream);
         else launch_variant<true, false>(a, ntiles, lds, stream);
