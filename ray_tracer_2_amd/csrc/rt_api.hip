@@ -53,6 +53,8 @@ struct rt_handle {
     float4* image = nullptr;
     Counters* counters = nullptr;
     uint32_t* work_counters = nullptr;  // ring of per-launch tile counters
+    uint32_t* pixel_cache_mem = nullptr;  // primary-ray cache when LDS has no room (persistent kernel)
+    size_t pixel_cache_words = 0;
     uint32_t work_slot = 0;
     int kernel_variant = -1;  // -1 auto, 0 persistent + lane refill, 1 one wave per tile
     // tile-cost feedback: rays per tile of the previous frame order the next frame's tiles
@@ -78,6 +80,8 @@ struct rt_handle {
     uint32_t n_meshes = 0, n_spheres = 0, n_textures = 0, n_nodes = 0, n_triangles = 0;
     uint32_t stack_entries = 1, tlas_entries = 1, n_items = 0;
     bool has_tlas = false;
+    int pixel_cache_opt = 1;  // option "pixel_cache"
+    int vote_eighths = 6, vote_patience = 1;  // options "vote_eighths", "vote_patience"
     int use_tlas = 1;  // option "tlas": 0 = every mesh is a single item (takes effect at the next upload)
     rt_camera_uniform camera{};
     int count_tests = 0;
@@ -245,6 +249,7 @@ void rt_destroy(rt_handle* h) {
     if (h->multi_event) (void)hipEventDestroy(h->multi_event);
     free_dev(h->counters);
     free_dev(h->work_counters);
+    free_dev(h->pixel_cache_mem);
     free_dev(h->tile_cost[0]);
     free_dev(h->tile_cost[1]);
     free_dev(h->tile_order);
@@ -537,7 +542,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->n_items = (uint32_t)items.size();
         // LDS residency: blob + the four waves' stacks within the per-workgroup budget
         uint64_t stacks = ((uint64_t)h->stack_entries * 128u + (uint64_t)h->tlas_entries * 64u) * sizeof(uint32_t) * WAVES_PER_BLOCK +
-                          8u * 3u * 4u * WAVES_PER_BLOCK;
+                          8u * 3u * 4u * WAVES_PER_BLOCK + (uint64_t)PIXEL_CACHE_DWORDS * 64u * 4u * WAVES_PER_BLOCK;
         h->lds_scene = (uint64_t)lay.bytes + stacks <= LDS_BUDGET_BYTES;
         h->camera = scene->camera;
         h->have_scene = true;
@@ -591,6 +596,14 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "tile_feedback") {
         h->tile_feedback = value ? 1 : 0;
         h->history_valid = false;
+    } else if (n == "vote_eighths") {
+        if (value < 0 || value > 8) return fail(h, RT_ERR_INVALID_ARGUMENT, "vote_eighths must be 0..8");
+        h->vote_eighths = value;
+    } else if (n == "vote_patience") {
+        if (value < 0) return fail(h, RT_ERR_INVALID_ARGUMENT, "vote_patience must be >= 0");
+        h->vote_patience = value;
+    } else if (n == "pixel_cache") {
+        h->pixel_cache_opt = value ? 1 : 0;
     } else if (n == "tlas") {
         h->use_tlas = value ? 1 : 0;
     } else if (n == "cull_roots") {
@@ -635,6 +648,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.lds_scene = (h->lds_scene && !h->force_global) ? 1u : 0u;
     a.cull_roots = (h->roots_are_unions && (h->cull_roots == 1 || (h->cull_roots < 0 && h->n_meshes >= 16))) ? 1u : 0u;
     a.many_mesh = (h->has_tlas || a.cull_roots) ? 1u : 0u;
+    // the per-lane primary-ray cache is used when it still leaves room for 4 workgroups per CU
     a.textures = h->textures;
     a.srgb_lut = h->srgb_lut;
     a.image = h->image;
@@ -656,6 +670,15 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     const uint32_t resident_waves = h->persistent_blocks * WAVES_PER_BLOCK;
     a.kernel_variant = h->kernel_variant >= 0 ? (uint32_t)h->kernel_variant
                                               : ((uint64_t)a.tiles_x * a.tiles_y * 4 <= (uint64_t)resident_waves * 5 ? 1u : 0u);
+    // (all fields that size the LDS are set by now)
+    a.vote_eighths = (uint32_t)h->vote_eighths;
+    a.vote_patience = (uint32_t)h->vote_patience;
+    a.pixel_cache = 0;
+    a.pixel_cache_mem = nullptr;
+    if (h->pixel_cache_opt) {
+        a.pixel_cache = 1;
+        if (render_lds_bytes(a) > LDS_BUDGET_BYTES) a.pixel_cache = 0;  // no room in LDS
+    }
     a.persistent_blocks = h->persistent_blocks;
     {
         // workgroups that fit a CU's 160 KiB of LDS (4 when the register budget is the limit)
@@ -665,6 +688,18 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         if (per_cu < 1u) per_cu = 1u;
         const uint32_t fit = (h->persistent_blocks / 4u) * per_cu;
         if (fit < a.persistent_blocks && fit > 0) a.persistent_blocks = fit;
+    }
+    if (h->pixel_cache_opt && a.pixel_cache == 0 && a.kernel_variant == 0 && params->debug_flag == 0) {
+        // persistent kernel: a fixed number of waves, so the cache can live in global memory
+        const size_t need = (size_t)h->persistent_blocks * WAVES_PER_BLOCK * PIXEL_CACHE_DWORDS * 64u;
+        if (h->pixel_cache_words < need) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            free_dev(h->pixel_cache_mem);
+            HIP_TRY(h, hipMalloc((void**)&h->pixel_cache_mem, need * sizeof(uint32_t)));
+            h->pixel_cache_words = need;
+        }
+        a.pixel_cache = 2;
+        a.pixel_cache_mem = h->pixel_cache_mem;
     }
     // a fresh tile counter per launch (ring of 64: launches on one stream are ordered)
     h->work_slot = (h->work_slot + 1) & 63u;

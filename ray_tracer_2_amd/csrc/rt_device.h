@@ -77,6 +77,8 @@ constexpr uint32_t SPHERE_BYTES = 16;
 constexpr uint32_t LDS_BUDGET_BYTES = 40 * 1024;
 constexpr uint32_t BLOCK_THREADS = 256;
 constexpr uint32_t WAVES_PER_BLOCK = BLOCK_THREADS / 64;
+// Per-lane primary-ray cache (see path_step): ro, rd, hit record, state word.
+constexpr uint32_t PIXEL_CACHE_DWORDS = 18;
 
 struct DTexture {
     const uint8_t* rgba8;
@@ -107,6 +109,11 @@ struct RenderArgs {
     uint32_t stack_entries;  // per-lane BVH stack depth (2 dwords per entry)
     uint32_t tlas_entries;   // per-lane TLAS stack depth (1 dword per entry), >= 1
     uint32_t many_mesh;      // 1 => use the kernels with top-level trees / root-box culling compiled in
+    uint32_t pixel_cache;    // per-lane primary-ray cache (PIXEL_CACHE_DWORDS per lane): 0 off, 1 in LDS,
+                             // 2 in `pixel_cache_mem` (persistent kernel only, when LDS has no room)
+    uint32_t* pixel_cache_mem;
+    uint32_t vote_eighths;   // intersection vote: run when wanting lanes * 8 >= lanes * vote_eighths
+    uint32_t vote_patience;  // ... or when somebody has waited this many iterations
     uint32_t strip_rank, strip_world;
     uint32_t tiles_x, tiles_y;  // 8x8 tiles of the (local) image
     uint32_t count_tests;       // 1 => accumulate node/triangle test counters

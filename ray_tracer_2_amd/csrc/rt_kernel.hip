@@ -659,6 +659,19 @@ DEV uint32_t* block_prologue(const RenderArgs& a) {
     return reinterpret_cast<uint32_t*>(lds_mem + stack_base) + wave * per_wave + lane;
 }
 
+// Per-lane primary-ray cache: behind the stacks and the cost tables (PIXEL_CACHE_DWORDS x 64
+// dwords per wave, lane-interleaved).
+template <bool LDS>
+DEV uint32_t* pixel_cache_of_lane(const RenderArgs& a) {
+    if (a.pixel_cache == 2u)  // global memory, same lane-interleaved layout per wave
+        return a.pixel_cache_mem + (size_t)(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * (PIXEL_CACHE_DWORDS * 64u) +
+               (threadIdx.x & 63u);
+    const uint32_t stack_base = LDS ? (a.lay.bytes >> 4) : 0u;  // float4 units
+    const uint32_t per_wave = (a.stack_entries ? a.stack_entries : 1u) * 128u + a.tlas_entries * 64u;
+    return reinterpret_cast<uint32_t*>(lds_mem + stack_base) + WAVES_PER_BLOCK * (per_wave + 8u * 3u) +
+           (threadIdx.x >> 6) * (PIXEL_CACHE_DWORDS * 64u) + (threadIdx.x & 63u);
+}
+
 // The persistent kernel's per-wave tile-cost tables follow the stacks.
 template <bool LDS>
 DEV uint32_t* cost_table_of_wave(const RenderArgs& a) {
@@ -729,23 +742,67 @@ DEV void pixel_begin(const RenderArgs& a, const CameraConsts& c, PixelState& s, 
     s.meta = 0;
 }
 
+// Called when a lane takes a new pixel: computes the pixel's constant primary ray when the
+// camera has no jitter and no -0 is involved (see path_step), else marks the cache empty.
+DEV void pixel_cache_begin(const RenderArgs& a, const CameraConsts& c, const PixelState& s, uint32_t* pc) {
+    if (!a.pixel_cache) return;
+    auto not_neg_zero = [](float x) { return __float_as_uint(x) != 0x80000000u; };
+    auto finite3 = [](f3 v) { return rtm::abs_(v.x) < INF && rtm::abs_(v.y) < INF && rtm::abs_(v.z) < INF; };
+    const bool constant_ray = __float_as_uint(a.camera.defocus_strength) == 0u &&
+                              __float_as_uint(a.camera.diverge_strength) == 0u && finite3(c.right) && finite3(c.up) &&
+                              not_neg_zero(c.origin.x) && not_neg_zero(c.origin.y) && not_neg_zero(c.origin.z) &&
+                              not_neg_zero(s.focus.x) && not_neg_zero(s.focus.y) && not_neg_zero(s.focus.z);
+    if (constant_ray) {
+        // x + (+-0) + (+-0) is x for x != 0 and +0 for x = +0: the jitter signs cannot matter
+        const f3 ro = (c.origin + c.right * 0.0f) + c.up * 0.0f;
+        const f3 jfp = (s.focus + c.right * 0.0f) + c.up * 0.0f;
+        f3 rd = normalize3(jfp - ro);
+        rd = normalize3(rd);  // wgsl:400
+        pc[0] = __float_as_uint(ro.x); pc[64] = __float_as_uint(ro.y); pc[128] = __float_as_uint(ro.z);
+        pc[192] = __float_as_uint(rd.x); pc[256] = __float_as_uint(rd.y); pc[320] = __float_as_uint(rd.z);
+        pc[17 * 64] = 0x10u;
+    } else {
+        pc[17 * 64] = 0u;
+    }
+}
+
 // One iteration of the per-lane state machine: (start the next sample) + one
 // path segment + its shading.  Returns true when the pixel's last sample ended.
 template <bool LDS, bool STATS, bool TLAS>
-DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, uint32_t* stack,
-                   uint32_t& n_segments, int& node_tests, int& tri_tests) {
+DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, uint32_t* stack, uint32_t* pc,
+                   uint32_t& starve, uint32_t& n_segments, int& node_tests, int& tri_tests) {
     const int32_t nb = a.params.number_of_bounces;
+    // Primary-ray cache.  With defocus_strength = diverge_strength = +0 (the default camera) the
+    // camera jitter is +-0, and unless a component of the camera origin or of the pixel's focus
+    // point is -0 the sums `origin + right*j.x + up*j.y` do not depend on those signs: every
+    // sample of the pixel starts with the same ray (pixel_cache_begin computes it once).  The
+    // ray and its intersection (a pure function of the ray) are memoised per lane in LDS:
+    // pc[0..5] = ro, rd, pc[6..16] = hit record, pc[17] = state (bit 4 ray valid, bit 5 hit
+    // valid).  Same inputs, same bits; the four RNG draws are still made.  Counter builds
+    // (STATS) re-intersect so that the node/triangle test counters stay the shader's.
+    const bool cache_on = a.pixel_cache != 0;  // wave-uniform
+    bool reuse_hit = false;
     DIAG(0);
     if (s.fresh) {  // wgsl:487-495: next sample of this pixel
         DIAG(1);
-        float jx, jy;
-        disk_jitter(s.rng, a.camera.defocus_strength, c.sx, jx, jy);
-        s.ro = (c.origin + c.right * jx) + c.up * jy;
-        float kx, ky;
-        disk_jitter(s.rng, a.camera.diverge_strength, c.sx, kx, ky);
-        f3 jfp = (s.focus + c.right * kx) + c.up * ky;
-        s.rd = normalize3(jfp - s.ro);
-        s.rd = normalize3(s.rd);  // wgsl:400
+        const uint32_t st = cache_on ? pc[17 * 64] : 0u;
+        if (st & 0x10u) {
+            (void)next_random_number(s.rng);  // the two disks' angle and radius draws
+            (void)next_random_number(s.rng);
+            (void)next_random_number(s.rng);
+            (void)next_random_number(s.rng);
+            s.ro = f3{__uint_as_float(pc[0]), __uint_as_float(pc[64]), __uint_as_float(pc[128])};
+            s.rd = f3{__uint_as_float(pc[192]), __uint_as_float(pc[256]), __uint_as_float(pc[320])};
+            reuse_hit = !STATS && (st & 0x20u) != 0u;
+        } else {
+            float jx, jy, kx, ky;
+            disk_jitter(s.rng, a.camera.defocus_strength, c.sx, jx, jy);
+            disk_jitter(s.rng, a.camera.diverge_strength, c.sx, kx, ky);
+            s.ro = (c.origin + c.right * jx) + c.up * jy;
+            f3 jfp = (s.focus + c.right * kx) + c.up * ky;
+            s.rd = normalize3(jfp - s.ro);
+            s.rd = normalize3(s.rd);  // wgsl:400
+        }
         s.T = f4{1, 1, 1, 1};
         s.light = f4{0, 0, 0, 0};
         s.seg = 0;
@@ -753,7 +810,44 @@ DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, ui
     }
     bool end_path = true;
     if (s.seg <= nb) {
-        Hit hit = intersect_scene<LDS, STATS, TLAS>(a, s.ro, s.rd, stack, node_tests, tri_tests);
+        // Intersection vote.  Lanes whose segment is a cached primary ray need no traversal; the
+        // others do.  The traversal is the expensive part of an iteration and the wave pays for
+        // it whenever a single lane needs it, so it only runs when at least half of the lanes
+        // here want it (or somebody has already waited once); the waiting lanes simply take
+        // their turn in the next iteration, by which time the cached-primary lanes have moved
+        // on to secondary segments and want it too.  Pure scheduling: no lane's sequence of
+        // operations changes.
+        if (cache_on) {
+            const uint32_t n_here = (uint32_t)__popcll(__ballot(true));
+            const uint32_t n_want = (uint32_t)__popcll(__ballot(!reuse_hit));
+            const bool run = n_want * 8u >= n_here * a.vote_eighths || starve >= a.vote_patience;
+            starve = (n_want != 0u && !run) ? starve + 1u : 0u;
+            if (!reuse_hit && !run) return false;  // wait; nothing about this lane has changed
+        }
+        Hit hit;
+        if (reuse_hit) {
+            hit.dst = __uint_as_float(pc[6 * 64]);
+            hit.point = f3{__uint_as_float(pc[7 * 64]), __uint_as_float(pc[8 * 64]), __uint_as_float(pc[9 * 64])};
+            hit.normal = f3{__uint_as_float(pc[10 * 64]), __uint_as_float(pc[11 * 64]), __uint_as_float(pc[12 * 64])};
+            hit.u = __uint_as_float(pc[13 * 64]);
+            hit.v = __uint_as_float(pc[14 * 64]);
+            hit.mat_off = pc[15 * 64];
+            const uint32_t fl = pc[16 * 64];
+            hit.hit = (fl & 1u) != 0u;
+            hit.backface = (fl & 2u) != 0u;
+        } else {
+            hit = intersect_scene<LDS, STATS, TLAS>(a, s.ro, s.rd, stack, node_tests, tri_tests);
+            if (cache_on && !STATS && s.seg == 0 && (pc[17 * 64] & 0x10u) != 0u) {  // the cached ray's hit
+                pc[6 * 64] = __float_as_uint(hit.dst);
+                pc[7 * 64] = __float_as_uint(hit.point.x); pc[8 * 64] = __float_as_uint(hit.point.y); pc[9 * 64] = __float_as_uint(hit.point.z);
+                pc[10 * 64] = __float_as_uint(hit.normal.x); pc[11 * 64] = __float_as_uint(hit.normal.y); pc[12 * 64] = __float_as_uint(hit.normal.z);
+                pc[13 * 64] = __float_as_uint(hit.u);
+                pc[14 * 64] = __float_as_uint(hit.v);
+                pc[15 * 64] = hit.mat_off;
+                pc[16 * 64] = (hit.hit ? 1u : 0u) | (hit.backface ? 2u : 0u);
+                pc[17 * 64] |= 0x20u;
+            }
+        }
         n_segments += 1;
         if ((s.meta & 0xffffu) != 0xffffu) s.meta += 1;
         if (!hit.hit) {
@@ -897,11 +991,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     const bool valid = tile_ok && px.valid;
     PixelState s;
     pixel_begin(a, cam, s, px.x, px.y, px.out_row);
+    uint32_t* pc = pixel_cache_of_lane<LDS>(a);
+    pixel_cache_begin(a, cam, s, pc);
+    uint32_t starve = 0;
     bool active = valid && a.params.rays_per_pixel > 0;
     uint32_t n_segments = 0;
     int node_tests = 0, tri_tests = 0;
     while (active) {
-        if (path_step<LDS, STATS, TLAS>(a, cam, s, stack, n_segments, node_tests, tri_tests)) active = false;
+        if (path_step<LDS, STATS, TLAS>(a, cam, s, stack, pc, starve, n_segments, node_tests, tri_tests)) active = false;
     }
     if (valid) pixel_finish(a, s);
     if (a.tile_cost && tile_ok) {  // one store per wave: the tile's rays
@@ -939,6 +1036,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
     // this wave's tile-cost table sits behind the workgroup's traversal stacks
     uint32_t* cost_tbl = cost_table_of_wave<LDS>(a);
     if (lane < COST_SLOTS * 3u) cost_tbl[lane] = 0u;
+    uint32_t* pc = pixel_cache_of_lane<LDS>(a);
+    uint32_t starve = 0;
     uint32_t pull_seq = 0;
 
     for (;;) {
@@ -967,6 +1066,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                     if (px.valid) {
                         DIAG(15);
                         pixel_begin(a, cam, s, px.x, px.y, px.out_row);
+                        pixel_cache_begin(a, cam, s, pc);
                         s.meta = (pull_seq & (COST_SLOTS - 1u)) << 16;
                         if (have_samples) {
                             active = true;
@@ -987,7 +1087,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
             continue;
         }
         if (active) {
-            if (path_step<LDS, STATS, TLAS>(a, cam, s, stack, n_segments, node_tests, tri_tests)) {
+            if (path_step<LDS, STATS, TLAS>(a, cam, s, stack, pc, starve, n_segments, node_tests, tri_tests)) {
                 DIAG(16);
                 pixel_finish(a, s);
                 if (a.tile_cost) tile_cost_add(a, cost_tbl, s);
@@ -1172,7 +1272,8 @@ size_t render_lds_bytes(const RenderArgs& a) {
     size_t stacks = ((size_t)(a.stack_entries ? a.stack_entries : 1u) * 128u + (size_t)a.tlas_entries * 64u) *
                     sizeof(uint32_t) * WAVES_PER_BLOCK;
     size_t cost_tables = 8u * 3u * sizeof(uint32_t) * WAVES_PER_BLOCK;
-    return stacks + cost_tables + (a.lds_scene ? a.lay.bytes : 0u);
+    size_t cache = a.pixel_cache == 1u ? (size_t)PIXEL_CACHE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
+    return stacks + cost_tables + cache + (a.lds_scene ? a.lay.bytes : 0u);
 }
 
 // Dynamic LDS above 64 KiB (deep-BVH stacks) has to be opted into per kernel.

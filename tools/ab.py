@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ray_tracer_2_amd as rt  # noqa: E402
 
-ALIAS = {"variant": "kernel_variant", "blocks": "persistent_blocks", "lds": "lds_scene", "fb": "tile_feedback", "cull": "cull_roots"}
-DEFAULTS = {"kernel_variant": -1, "lds_scene": 1, "tile_feedback": 1, "cull_roots": -1}
+ALIAS = {"variant": "kernel_variant", "blocks": "persistent_blocks", "lds": "lds_scene", "fb": "tile_feedback", "cull": "cull_roots", "pc": "pixel_cache", "ve": "vote_eighths", "vp": "vote_patience"}
+DEFAULTS = {"kernel_variant": -1, "lds_scene": 1, "tile_feedback": 1, "cull_roots": -1, "pixel_cache": 1, "vote_eighths": 6, "vote_patience": 1}
 
 
 def main():

@@ -8,8 +8,9 @@ W, H = 1920, 1080
 arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
 tr = rt.RayTracer(0, W, H)
 tr.load_scene(arrays)
-for world in (8, 4, 2, 1):
-    for blocks in (256, 384, 512, 640, 768, 1024):
+tr.set_option("kernel_variant", 0)
+for world in (8, 4):
+    for blocks in (256, 384, 512, 640, 768, 896, 1024):
         tr.set_option("persistent_blocks", blocks)
         ts = []
         for r in range(4):
