@@ -542,7 +542,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->n_items = (uint32_t)items.size();
         // LDS residency: blob + the four waves' stacks within the per-workgroup budget
         uint64_t stacks = ((uint64_t)h->stack_entries * 128u + (uint64_t)h->tlas_entries * 64u) * sizeof(uint32_t) * WAVES_PER_BLOCK +
-                          8u * 3u * 4u * WAVES_PER_BLOCK + (uint64_t)PIXEL_CACHE_DWORDS * 64u * 4u * WAVES_PER_BLOCK;
+                          8u * 3u * 4u * WAVES_PER_BLOCK + (uint64_t)(LANE_STATE_DWORDS + PIXEL_MEMO_DWORDS) * 64u * 4u * WAVES_PER_BLOCK;
         h->lds_scene = (uint64_t)lay.bytes + stacks <= LDS_BUDGET_BYTES;
         h->camera = scene->camera;
         h->have_scene = true;
@@ -643,6 +643,11 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     RenderArgs a{};
     a.params = *params;
     a.camera = h->camera;
+    for (int k = 0; k < 3; ++k) {  // see pixel_cache_begin: the same IEEE operations, unfused
+        volatile float rz = h->camera.cam_to_world[0][k] * 0.0f, uz = h->camera.cam_to_world[1][k] * 0.0f;
+        volatile float t = h->camera.cam_to_world[3][k] + rz;
+        a.memo_ro[k] = t + uz;
+    }
     a.blob = h->blob;
     a.lay = h->lay;
     a.lds_scene = (h->lds_scene && !h->force_global) ? 1u : 0u;
@@ -691,7 +696,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     }
     if (h->pixel_cache_opt && a.pixel_cache == 0 && a.kernel_variant == 0 && params->debug_flag == 0) {
         // persistent kernel: a fixed number of waves, so the cache can live in global memory
-        const size_t need = (size_t)h->persistent_blocks * WAVES_PER_BLOCK * PIXEL_CACHE_DWORDS * 64u;
+        const size_t need = (size_t)h->persistent_blocks * WAVES_PER_BLOCK * PIXEL_MEMO_DWORDS * 64u;
         if (h->pixel_cache_words < need) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             free_dev(h->pixel_cache_mem);

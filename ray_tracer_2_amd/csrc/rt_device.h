@@ -77,8 +77,13 @@ constexpr uint32_t SPHERE_BYTES = 16;
 constexpr uint32_t LDS_BUDGET_BYTES = 40 * 1024;
 constexpr uint32_t BLOCK_THREADS = 256;
 constexpr uint32_t WAVES_PER_BLOCK = BLOCK_THREADS / 64;
-// Per-lane primary-ray cache (see path_step): ro, rd, hit record, state word.
-constexpr uint32_t PIXEL_CACHE_DWORDS = 18;
+// Per-lane state kept in LDS instead of registers (see path_step): the pixel's running sum
+// `total`, 4 floats.  It is touched once per path but would otherwise occupy 4 VGPRs across the
+// whole traversal.
+constexpr uint32_t LANE_STATE_DWORDS = 4;
+// Per-lane primary-ray memo (see path_step): rd, hit record (dst, point, normal, u, v), and
+// one word = mat_off | hit | backface << 1 | ray valid << 2 | hit valid << 3.
+constexpr uint32_t PIXEL_MEMO_DWORDS = 13;
 
 struct DTexture {
     const uint8_t* rgba8;
@@ -109,9 +114,10 @@ struct RenderArgs {
     uint32_t stack_entries;  // per-lane BVH stack depth (2 dwords per entry)
     uint32_t tlas_entries;   // per-lane TLAS stack depth (1 dword per entry), >= 1
     uint32_t many_mesh;      // 1 => use the kernels with top-level trees / root-box culling compiled in
-    uint32_t pixel_cache;    // per-lane primary-ray cache (PIXEL_CACHE_DWORDS per lane): 0 off, 1 in LDS,
+    uint32_t pixel_cache;    // per-lane primary-ray memo (PIXEL_MEMO_DWORDS per lane): 0 off, 1 in LDS,
                              // 2 in `pixel_cache_mem` (persistent kernel only, when LDS has no room)
     uint32_t* pixel_cache_mem;
+    float memo_ro[3];        // (origin + right * 0) + up * 0: the memoised primary rays' common origin
     uint32_t vote_eighths;   // intersection vote: run when wanting lanes * 8 >= lanes * vote_eighths
     uint32_t vote_patience;  // ... or when somebody has waited this many iterations
     uint32_t strip_rank, strip_world;

@@ -109,7 +109,8 @@ DEV float smoothstep_(float lo, float hi, float x) {
     return (t * t) * (3.0f - 2.0f * t);
 }
 // (mat4 * vec4(v, w)).xyz, column-major m[col*4 + row]
-DEV f3 mat_xyz(const float* __restrict__ m, f3 v, float w) {
+template <class P>
+DEV f3 mat_xyz(P m, f3 v, float w) {
     f3 r;
     r.x = ((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12] * w;
     r.y = ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13] * w;
@@ -618,7 +619,8 @@ struct PixelCoord {
     bool valid;
 };
 
-DEV PixelCoord pixel_of(const RenderArgs& a, uint32_t tile, uint32_t w) {
+template <class A>
+DEV PixelCoord pixel_of(const A& a, uint32_t tile, uint32_t w) {
     const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     PixelCoord p;
     p.x = tx * 8u + (w & 7u);
@@ -630,7 +632,8 @@ DEV PixelCoord pixel_of(const RenderArgs& a, uint32_t tile, uint32_t w) {
 }
 
 // wgsl:154-161
-DEV void store_texel(const RenderArgs& a, uint32_t x, uint32_t out_row, f4 cur) {
+template <class A>
+DEV void store_texel(const A& a, uint32_t x, uint32_t out_row, f4 cur) {
     float4* texel = a.image + (size_t)out_row * a.params.width + x;
     if (a.params.frames >= 1) {
         float4 prev = *texel;
@@ -643,41 +646,39 @@ DEV void store_texel(const RenderArgs& a, uint32_t x, uint32_t out_row, f4 cur) 
     }
 }
 
+// LDS map of a workgroup: [scene blob (LDS kernels)] [4 wave regions] [4 tile-cost tables].
+// A wave region is lane-interleaved (dword k of lane l at [k * 64 + l], conflict-free):
+//   [primary-ray memo, PIXEL_MEMO_DWORDS x 64, only when pixel_cache == 1]
+//   [lane state, LANE_STATE_DWORDS x 64] [BVH stack, stack_entries x 2 x 64] [TLAS stack, tlas_entries x 64]
+// Everything is addressed from ONE per-lane pointer (the lane-state base) with immediate
+// offsets, so the whole map costs a single VGPR.
+DEV uint32_t wave_region_dwords(const RenderArgs& a) {
+    return (a.pixel_cache == 1u ? PIXEL_MEMO_DWORDS * 64u : 0u) + LANE_STATE_DWORDS * 64u +
+           (a.stack_entries ? a.stack_entries : 1u) * 128u + a.tlas_entries * 64u;
+}
+
 // Stage the scene blob into LDS (coalesced 16-byte loads, whole workgroup) and
-// return this wave's stack column base.
+// return this lane's base pointer (its lane state; see the map above).
 template <bool LDS>
 DEV uint32_t* block_prologue(const RenderArgs& a) {
-    uint32_t stack_base = 0;  // in float4 units
+    uint32_t base = 0;  // in float4 units
     if constexpr (LDS) {
         const uint32_t n16 = a.lay.bytes >> 4;
         for (uint32_t i = threadIdx.x; i < n16; i += BLOCK_THREADS) lds_mem[i] = a.blob[i];
         __syncthreads();
-        stack_base = n16;
+        base = n16;
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t per_wave = (a.stack_entries ? a.stack_entries : 1u) * 128u + a.tlas_entries * 64u;  // dwords
-    return reinterpret_cast<uint32_t*>(lds_mem + stack_base) + wave * per_wave + lane;
+    return reinterpret_cast<uint32_t*>(lds_mem + base) + wave * wave_region_dwords(a) +
+           (a.pixel_cache == 1u ? PIXEL_MEMO_DWORDS * 64u : 0u) + lane;
 }
+DEV uint32_t* stack_of(uint32_t* lane_base) { return lane_base + LANE_STATE_DWORDS * 64u; }
 
-// Per-lane primary-ray cache: behind the stacks and the cost tables (PIXEL_CACHE_DWORDS x 64
-// dwords per wave, lane-interleaved).
-template <bool LDS>
-DEV uint32_t* pixel_cache_of_lane(const RenderArgs& a) {
-    if (a.pixel_cache == 2u)  // global memory, same lane-interleaved layout per wave
-        return a.pixel_cache_mem + (size_t)(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * (PIXEL_CACHE_DWORDS * 64u) +
-               (threadIdx.x & 63u);
-    const uint32_t stack_base = LDS ? (a.lay.bytes >> 4) : 0u;  // float4 units
-    const uint32_t per_wave = (a.stack_entries ? a.stack_entries : 1u) * 128u + a.tlas_entries * 64u;
-    return reinterpret_cast<uint32_t*>(lds_mem + stack_base) + WAVES_PER_BLOCK * (per_wave + 8u * 3u) +
-           (threadIdx.x >> 6) * (PIXEL_CACHE_DWORDS * 64u) + (threadIdx.x & 63u);
-}
-
-// The persistent kernel's per-wave tile-cost tables follow the stacks.
+// The persistent kernel's per-wave tile-cost tables follow the wave regions.
 template <bool LDS>
 DEV uint32_t* cost_table_of_wave(const RenderArgs& a) {
-    const uint32_t stack_base = LDS ? (a.lay.bytes >> 4) : 0u;  // float4 units
-    const uint32_t per_wave = (a.stack_entries ? a.stack_entries : 1u) * 128u + a.tlas_entries * 64u;
-    return reinterpret_cast<uint32_t*>(lds_mem + stack_base) + WAVES_PER_BLOCK * per_wave +
+    const uint32_t base = LDS ? (a.lay.bytes >> 4) : 0u;  // float4 units
+    return reinterpret_cast<uint32_t*>(lds_mem + base) + WAVES_PER_BLOCK * wave_region_dwords(a) +
            (threadIdx.x >> 6) * (8u * 3u);
 }
 
@@ -693,12 +694,12 @@ struct CameraConsts {  // wave-uniform
     float sx, sy;
 };
 
-DEV CameraConsts camera_consts(const RenderArgs& a) {
-    const float* __restrict__ c2w = &a.camera.cam_to_world[0][0];
+template <class A>
+DEV CameraConsts camera_consts(const A& a) {
     CameraConsts c;
-    c.origin = f3{c2w[12], c2w[13], c2w[14]};
-    c.right = f3{c2w[0], c2w[1], c2w[2]};
-    c.up = f3{c2w[4], c2w[5], c2w[6]};
+    c.origin = f3{a.camera.cam_to_world[3][0], a.camera.cam_to_world[3][1], a.camera.cam_to_world[3][2]};
+    c.right = f3{a.camera.cam_to_world[0][0], a.camera.cam_to_world[0][1], a.camera.cam_to_world[0][2]};
+    c.up = f3{a.camera.cam_to_world[1][0], a.camera.cam_to_world[1][1], a.camera.cam_to_world[1][2]};
     c.sx = (float)a.params.width;
     c.sy = (float)a.params.height;
     return c;
@@ -706,11 +707,10 @@ DEV CameraConsts camera_consts(const RenderArgs& a) {
 
 struct PixelState {
     uint32_t x, out_row;   // where the texel goes
-    f3 focus;              // wgsl:482
     uint32_t rng;          // wgsl:475, one stream per pixel
-    f4 total;              // wgsl:486
     int32_t j;             // sample index (wgsl:487)
-    // current path (wgsl:398-471)
+    // current path (wgsl:398-471); `total` (wgsl:486) lives in the lane's LDS state region
+    // (LANE_STATE_DWORDS), not in registers
     f3 ro, rd;
     f4 T, light;
     int32_t seg;
@@ -718,20 +718,32 @@ struct PixelState {
     uint32_t meta;         // rays of this pixel so far (bits 0-15, saturating) | cost-table slot (bits 16-18)
 };
 
-// wgsl:475-484 for pixel (x, y) of the full frame
-DEV void pixel_begin(const RenderArgs& a, const CameraConsts& c, PixelState& s, uint32_t x, uint32_t y,
-                     uint32_t out_row) {
+// wgsl:479-482: the pixel's focus point
+template <class A>
+DEV f3 focus_point_of(const A& a, const CameraConsts& c, uint32_t x, uint32_t y) {
+    const float fx = (float)x, fy = (float)y;
+    const float uvx = fx / (c.sx - 1.0f), uvy = fy / (c.sy - 1.0f);
+    const f3 local_focus = f3{uvx - 0.5f, uvy - 0.5f, 1.0f} *
+                           f3{a.camera.view_params[0], a.camera.view_params[1], a.camera.view_params[2]};
+    return mat_xyz(&a.camera.cam_to_world[0][0], local_focus, 1.0f);
+}
+// frame row of a pixel from its output row (they differ in the compact strip layout)
+template <class A>
+DEV uint32_t frame_row_of(const A& a, uint32_t out_row) {
+    return a.strip_world > 1u ? ((out_row >> 3) * a.strip_world + a.strip_rank) * 8u + (out_row & 7u) : out_row;
+}
+
+// wgsl:475 for pixel (x, y) of the full frame
+template <class A>
+DEV void pixel_begin(const A& a, const CameraConsts& c, PixelState& s, uint32_t* ls, uint32_t x,
+                     uint32_t y, uint32_t out_row) {
     const float fx = (float)x, fy = (float)y;
     const int32_t fr = a.params.frames;
     const uint32_t absf = fr < 0 ? 0u - (uint32_t)fr : (uint32_t)fr;
     s.rng = (uint32_t)(fy * c.sx + fx) + absf * 719393u;
-    const float uvx = fx / (c.sx - 1.0f), uvy = fy / (c.sy - 1.0f);
-    const f3 local_focus = f3{uvx - 0.5f, uvy - 0.5f, 1.0f} *
-                           f3{a.camera.view_params[0], a.camera.view_params[1], a.camera.view_params[2]};
-    s.focus = mat_xyz(&a.camera.cam_to_world[0][0], local_focus, 1.0f);
     s.x = x;
     s.out_row = out_row;
-    s.total = f4{0, 0, 0, 0};
+    ls[0] = 0u; ls[64] = 0u; ls[128] = 0u; ls[192] = 0u;  // total = 0
     s.j = 0;
     s.fresh = true;
     s.seg = 0;
@@ -742,64 +754,107 @@ DEV void pixel_begin(const RenderArgs& a, const CameraConsts& c, PixelState& s, 
     s.meta = 0;
 }
 
+enum : uint32_t { MEMO_HIT = 1u, MEMO_BACKFACE = 2u, MEMO_RAY = 4u, MEMO_HIT_VALID = 8u };
+
+// Kernel arguments for the rarely executed paths (taking a new pixel, finishing one, camera
+// jitter): re-read from the kernarg segment where they are needed.  The asm keeps the compiler
+// from hoisting those loads -- and every wave-uniform float computation that depends on them
+// (there is no scalar float ALU: they would be parked in VGPRs) -- out of the render loop.
+typedef const __attribute__((address_space(4))) RenderArgs ColdArgs;
+DEV ColdArgs& cold_args() {
+    ColdArgs* p = (ColdArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;
+}
+
+// This lane's primary-ray memo: in LDS right below the lane state (pixel_cache == 1), or in
+// global memory (== 2; the pointer is rebuilt per use rather than kept in two VGPRs).  `f`
+// is instantiated once per address space, so the LDS copy uses ds_ and the other global_
+// instructions (a runtime-selected pointer would mean flat_ accesses).
+template <class F>
+DEV void with_memo(const RenderArgs& a, uint32_t* ls, F&& f) {
+    if (a.pixel_cache == 2u) {
+        uint32_t t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        typedef __attribute__((address_space(1))) uint32_t* GlobalPtr;
+        f((GlobalPtr)a.pixel_cache_mem + (size_t)(blockIdx.x * WAVES_PER_BLOCK + (t >> 6)) * (PIXEL_MEMO_DWORDS * 64u) +
+          (t & 63u));
+    } else {
+        typedef __attribute__((address_space(3))) uint32_t* LdsPtr;
+        f((LdsPtr)(ls - PIXEL_MEMO_DWORDS * 64u));
+    }
+}
+
 // Called when a lane takes a new pixel: computes the pixel's constant primary ray when the
-// camera has no jitter and no -0 is involved (see path_step), else marks the cache empty.
-DEV void pixel_cache_begin(const RenderArgs& a, const CameraConsts& c, const PixelState& s, uint32_t* pc) {
+// camera has no jitter and no -0 is involved (see path_step), else marks the memo empty.
+template <class A>
+DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts& c, const PixelState& s, uint32_t* ls) {
     if (!a.pixel_cache) return;
+    const f3 focus = focus_point_of(ca, c, s.x, frame_row_of(ca, s.out_row));
     auto not_neg_zero = [](float x) { return __float_as_uint(x) != 0x80000000u; };
     auto finite3 = [](f3 v) { return rtm::abs_(v.x) < INF && rtm::abs_(v.y) < INF && rtm::abs_(v.z) < INF; };
-    const bool constant_ray = __float_as_uint(a.camera.defocus_strength) == 0u &&
-                              __float_as_uint(a.camera.diverge_strength) == 0u && finite3(c.right) && finite3(c.up) &&
+    const bool constant_ray = __float_as_uint(ca.camera.defocus_strength) == 0u &&
+                              __float_as_uint(ca.camera.diverge_strength) == 0u && finite3(c.right) && finite3(c.up) &&
                               not_neg_zero(c.origin.x) && not_neg_zero(c.origin.y) && not_neg_zero(c.origin.z) &&
-                              not_neg_zero(s.focus.x) && not_neg_zero(s.focus.y) && not_neg_zero(s.focus.z);
+                              not_neg_zero(focus.x) && not_neg_zero(focus.y) && not_neg_zero(focus.z);
+    f3 rd{0, 0, 0};
     if (constant_ray) {
         // x + (+-0) + (+-0) is x for x != 0 and +0 for x = +0: the jitter signs cannot matter
+        // (so the origin is the same for every pixel: RenderArgs::memo_ro, computed by the host
+        // with these same operations)
         const f3 ro = (c.origin + c.right * 0.0f) + c.up * 0.0f;
-        const f3 jfp = (s.focus + c.right * 0.0f) + c.up * 0.0f;
-        f3 rd = normalize3(jfp - ro);
+        const f3 jfp = (focus + c.right * 0.0f) + c.up * 0.0f;
+        rd = normalize3(jfp - ro);
         rd = normalize3(rd);  // wgsl:400
-        pc[0] = __float_as_uint(ro.x); pc[64] = __float_as_uint(ro.y); pc[128] = __float_as_uint(ro.z);
-        pc[192] = __float_as_uint(rd.x); pc[256] = __float_as_uint(rd.y); pc[320] = __float_as_uint(rd.z);
-        pc[17 * 64] = 0x10u;
-    } else {
-        pc[17 * 64] = 0u;
     }
+    with_memo(a, ls, [&](auto pc) {
+        pc[0] = __float_as_uint(rd.x); pc[64] = __float_as_uint(rd.y); pc[128] = __float_as_uint(rd.z);
+        pc[12 * 64] = constant_ray ? MEMO_RAY : 0u;
+    });
 }
 
 // One iteration of the per-lane state machine: (start the next sample) + one
 // path segment + its shading.  Returns true when the pixel's last sample ended.
 template <bool LDS, bool STATS, bool TLAS>
-DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, uint32_t* stack, uint32_t* pc,
-                   uint32_t& starve, uint32_t& n_segments, int& node_tests, int& tri_tests) {
+DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
+                   int& node_tests, int& tri_tests) {
     const int32_t nb = a.params.number_of_bounces;
-    // Primary-ray cache.  With defocus_strength = diverge_strength = +0 (the default camera) the
+    uint32_t* stack = stack_of(ls);
+    // Primary-ray memo.  With defocus_strength = diverge_strength = +0 (the default camera) the
     // camera jitter is +-0, and unless a component of the camera origin or of the pixel's focus
     // point is -0 the sums `origin + right*j.x + up*j.y` do not depend on those signs: every
     // sample of the pixel starts with the same ray (pixel_cache_begin computes it once).  The
-    // ray and its intersection (a pure function of the ray) are memoised per lane in LDS:
-    // pc[0..5] = ro, rd, pc[6..16] = hit record, pc[17] = state (bit 4 ray valid, bit 5 hit
-    // valid).  Same inputs, same bits; the four RNG draws are still made.  Counter builds
-    // (STATS) re-intersect so that the node/triangle test counters stay the shader's.
+    // ray and its intersection (a pure function of the ray) are memoised per lane:
+    // pc[0..2] = rd, pc[3..11] = hit record, pc[12] = mat_off | MEMO_* flags.  Same inputs, same
+    // bits; the four RNG draws are still made.  Counter builds (STATS) re-intersect so that the
+    // node/triangle test counters stay the shader's.
     const bool cache_on = a.pixel_cache != 0;  // wave-uniform
     bool reuse_hit = false;
     DIAG(0);
     if (s.fresh) {  // wgsl:487-495: next sample of this pixel
         DIAG(1);
-        const uint32_t st = cache_on ? pc[17 * 64] : 0u;
-        if (st & 0x10u) {
+        uint32_t st = 0u;
+        if (cache_on)
+            with_memo(a, ls, [&](auto pc) {
+                st = pc[12 * 64];
+                s.rd = f3{__uint_as_float(pc[0]), __uint_as_float(pc[64]), __uint_as_float(pc[128])};
+            });
+        if (st & MEMO_RAY) {
             (void)next_random_number(s.rng);  // the two disks' angle and radius draws
             (void)next_random_number(s.rng);
             (void)next_random_number(s.rng);
             (void)next_random_number(s.rng);
-            s.ro = f3{__uint_as_float(pc[0]), __uint_as_float(pc[64]), __uint_as_float(pc[128])};
-            s.rd = f3{__uint_as_float(pc[192]), __uint_as_float(pc[256]), __uint_as_float(pc[320])};
-            reuse_hit = !STATS && (st & 0x20u) != 0u;
+            s.ro = f3{a.memo_ro[0], a.memo_ro[1], a.memo_ro[2]};
+            reuse_hit = !STATS && (st & MEMO_HIT_VALID) != 0u;
         } else {
+            ColdArgs& ca = cold_args();
+            const CameraConsts c = camera_consts(ca);
             float jx, jy, kx, ky;
-            disk_jitter(s.rng, a.camera.defocus_strength, c.sx, jx, jy);
-            disk_jitter(s.rng, a.camera.diverge_strength, c.sx, kx, ky);
+            disk_jitter(s.rng, ca.camera.defocus_strength, c.sx, jx, jy);
+            disk_jitter(s.rng, ca.camera.diverge_strength, c.sx, kx, ky);
             s.ro = (c.origin + c.right * jx) + c.up * jy;
-            f3 jfp = (s.focus + c.right * kx) + c.up * ky;
+            const f3 focus = focus_point_of(ca, c, s.x, frame_row_of(ca, s.out_row));
+            f3 jfp = (focus + c.right * kx) + c.up * ky;
             s.rd = normalize3(jfp - s.ro);
             s.rd = normalize3(s.rd);  // wgsl:400
         }
@@ -810,13 +865,12 @@ DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, ui
     }
     bool end_path = true;
     if (s.seg <= nb) {
-        // Intersection vote.  Lanes whose segment is a cached primary ray need no traversal; the
+        // Intersection vote.  Lanes whose segment is a memoised primary ray need no traversal; the
         // others do.  The traversal is the expensive part of an iteration and the wave pays for
-        // it whenever a single lane needs it, so it only runs when at least half of the lanes
-        // here want it (or somebody has already waited once); the waiting lanes simply take
-        // their turn in the next iteration, by which time the cached-primary lanes have moved
-        // on to secondary segments and want it too.  Pure scheduling: no lane's sequence of
-        // operations changes.
+        // it whenever a single lane needs it, so it only runs when enough of the lanes here want
+        // it (or somebody has already waited); the waiting lanes simply take their turn in the
+        // next iteration, by which time the memoised-primary lanes have moved on to secondary
+        // segments and want it too.  Pure scheduling: no lane's sequence of operations changes.
         if (cache_on) {
             const uint32_t n_here = (uint32_t)__popcll(__ballot(true));
             const uint32_t n_want = (uint32_t)__popcll(__ballot(!reuse_hit));
@@ -826,26 +880,31 @@ DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, ui
         }
         Hit hit;
         if (reuse_hit) {
-            hit.dst = __uint_as_float(pc[6 * 64]);
-            hit.point = f3{__uint_as_float(pc[7 * 64]), __uint_as_float(pc[8 * 64]), __uint_as_float(pc[9 * 64])};
-            hit.normal = f3{__uint_as_float(pc[10 * 64]), __uint_as_float(pc[11 * 64]), __uint_as_float(pc[12 * 64])};
-            hit.u = __uint_as_float(pc[13 * 64]);
-            hit.v = __uint_as_float(pc[14 * 64]);
-            hit.mat_off = pc[15 * 64];
-            const uint32_t fl = pc[16 * 64];
-            hit.hit = (fl & 1u) != 0u;
-            hit.backface = (fl & 2u) != 0u;
+            with_memo(a, ls, [&](auto pc) {
+                hit.dst = __uint_as_float(pc[3 * 64]);
+                hit.point = f3{__uint_as_float(pc[4 * 64]), __uint_as_float(pc[5 * 64]), __uint_as_float(pc[6 * 64])};
+                hit.normal = f3{__uint_as_float(pc[7 * 64]), __uint_as_float(pc[8 * 64]), __uint_as_float(pc[9 * 64])};
+                hit.u = __uint_as_float(pc[10 * 64]);
+                hit.v = __uint_as_float(pc[11 * 64]);
+                const uint32_t w = pc[12 * 64];
+                hit.mat_off = w & ~15u;  // material records are 16-byte aligned
+                hit.hit = (w & MEMO_HIT) != 0u;
+                hit.backface = (w & MEMO_BACKFACE) != 0u;
+            });
         } else {
             hit = intersect_scene<LDS, STATS, TLAS>(a, s.ro, s.rd, stack, node_tests, tri_tests);
-            if (cache_on && !STATS && s.seg == 0 && (pc[17 * 64] & 0x10u) != 0u) {  // the cached ray's hit
-                pc[6 * 64] = __float_as_uint(hit.dst);
-                pc[7 * 64] = __float_as_uint(hit.point.x); pc[8 * 64] = __float_as_uint(hit.point.y); pc[9 * 64] = __float_as_uint(hit.point.z);
-                pc[10 * 64] = __float_as_uint(hit.normal.x); pc[11 * 64] = __float_as_uint(hit.normal.y); pc[12 * 64] = __float_as_uint(hit.normal.z);
-                pc[13 * 64] = __float_as_uint(hit.u);
-                pc[14 * 64] = __float_as_uint(hit.v);
-                pc[15 * 64] = hit.mat_off;
-                pc[16 * 64] = (hit.hit ? 1u : 0u) | (hit.backface ? 2u : 0u);
-                pc[17 * 64] |= 0x20u;
+            if (cache_on && !STATS && s.seg == 0) {
+                with_memo(a, ls, [&](auto pc) {
+                    if ((pc[12 * 64] & MEMO_RAY) == 0u) return;
+                    // the memoised ray's hit
+                    pc[3 * 64] = __float_as_uint(hit.dst);
+                    pc[4 * 64] = __float_as_uint(hit.point.x); pc[5 * 64] = __float_as_uint(hit.point.y); pc[6 * 64] = __float_as_uint(hit.point.z);
+                    pc[7 * 64] = __float_as_uint(hit.normal.x); pc[8 * 64] = __float_as_uint(hit.normal.y); pc[9 * 64] = __float_as_uint(hit.normal.z);
+                    pc[10 * 64] = __float_as_uint(hit.u);
+                    pc[11 * 64] = __float_as_uint(hit.v);
+                    pc[12 * 64] = (hit.hit ? (hit.mat_off & ~15u) | MEMO_HIT : 0u) | (hit.backface ? MEMO_BACKFACE : 0u) |
+                                  MEMO_RAY | MEMO_HIT_VALID;
+                });
             }
         }
         n_segments += 1;
@@ -919,7 +978,10 @@ DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, ui
         }
     }
     if (end_path) {  // wgsl:496
-        s.total = s.total + s.light;
+        ls[0] = __float_as_uint(__uint_as_float(ls[0]) + s.light.x);  // total += incoming_light
+        ls[64] = __float_as_uint(__uint_as_float(ls[64]) + s.light.y);
+        ls[128] = __float_as_uint(__uint_as_float(ls[128]) + s.light.z);
+        ls[192] = __float_as_uint(__uint_as_float(ls[192]) + s.light.w);
         s.j += 1;
         s.fresh = true;
         return s.j >= a.params.rays_per_pixel;
@@ -928,9 +990,11 @@ DEV bool path_step(const RenderArgs& a, const CameraConsts& c, PixelState& s, ui
 }
 
 // wgsl:498 + 154-161
-DEV void pixel_finish(const RenderArgs& a, const PixelState& s) {
+template <class A>
+DEV void pixel_finish(const A& a, const PixelState& s, const uint32_t* ls) {
     float n = (float)a.params.rays_per_pixel;
-    store_texel(a, s.x, s.out_row, f4{s.total.x / n, s.total.y / n, s.total.z / n, s.total.w / n});
+    const f4 total{__uint_as_float(ls[0]), __uint_as_float(ls[64]), __uint_as_float(ls[128]), __uint_as_float(ls[192])};
+    store_texel(a, s.x, s.out_row, f4{total.x / n, total.y / n, total.z / n, total.w / n});
 }
 
 // Tile-cost feedback (rays per 8x8 tile, read by the next frame's scheduler).  A persistent
@@ -939,7 +1003,8 @@ DEV void pixel_finish(const RenderArgs& a, const PixelState& s) {
 // issues ONE global add per tile; only a tile evicted from the table while still in flight
 // falls back to per-pixel adds.  All updates are adds, so the total is exact either way.
 constexpr uint32_t COST_SLOTS = 8;
-DEV void tile_cost_pull(const RenderArgs& a, uint32_t* tbl, uint32_t slot, uint32_t tile) {
+template <class A>
+DEV void tile_cost_pull(const A& a, uint32_t* tbl, uint32_t slot, uint32_t tile) {
     const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const uint32_t y0 = (ty * a.strip_world + a.strip_rank) * 8u;
     const uint32_t vx = a.params.width - tx * 8u < 8u ? a.params.width - tx * 8u : 8u;
@@ -982,7 +1047,7 @@ DEV void flush_counters(const RenderArgs& a, uint32_t n_segments, int node_tests
 // tiles per workgroup.
 template <bool LDS, bool STATS, bool TLAS>
 __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_kernel(const RenderArgs a) {
-    uint32_t* stack = block_prologue<LDS>(a);
+    uint32_t* ls = block_prologue<LDS>(a);
     const CameraConsts cam = camera_consts(a);
     const uint32_t slot = xcd_remap(blockIdx.x, gridDim.x) * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const bool tile_ok = slot < a.tiles_x * a.tiles_y;
@@ -990,17 +1055,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     const PixelCoord px = pixel_of(a, tile, threadIdx.x & 63u);
     const bool valid = tile_ok && px.valid;
     PixelState s;
-    pixel_begin(a, cam, s, px.x, px.y, px.out_row);
-    uint32_t* pc = pixel_cache_of_lane<LDS>(a);
-    pixel_cache_begin(a, cam, s, pc);
+    pixel_begin(a, cam, s, ls, px.x, px.y, px.out_row);
+    pixel_cache_begin(a, a, cam, s, ls);
     uint32_t starve = 0;
     bool active = valid && a.params.rays_per_pixel > 0;
     uint32_t n_segments = 0;
     int node_tests = 0, tri_tests = 0;
     while (active) {
-        if (path_step<LDS, STATS, TLAS>(a, cam, s, stack, pc, starve, n_segments, node_tests, tri_tests)) active = false;
+        if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, node_tests, tri_tests)) active = false;
     }
-    if (valid) pixel_finish(a, s);
+    if (valid) pixel_finish(a, s, ls);
     if (a.tile_cost && tile_ok) {  // one store per wave: the tile's rays
         uint32_t sum = n_segments;
         for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
@@ -1020,23 +1084,21 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
 #if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
     const unsigned long long t_wave_start = __builtin_amdgcn_s_memrealtime();
 #endif
-    uint32_t* stack = block_prologue<LDS>(a);
+    uint32_t* ls = block_prologue<LDS>(a);
     const uint32_t lane = threadIdx.x & 63u;
-    const CameraConsts cam = camera_consts(a);
     const uint32_t n_tiles = a.tiles_x * a.tiles_y;
     const bool have_samples = a.params.rays_per_pixel > 0;
 
     uint32_t pool_base = 0, pool_left = 0;  // wave-uniform: pixels left in the current tile
     bool exhausted = false;
     PixelState s;
-    pixel_begin(a, cam, s, 0, 0, 0);
+    pixel_begin(a, camera_consts(a), s, ls, 0, 0, 0);
     bool active = false;
     uint32_t n_segments = 0;
     int node_tests = 0, tri_tests = 0;
     // this wave's tile-cost table sits behind the workgroup's traversal stacks
     uint32_t* cost_tbl = cost_table_of_wave<LDS>(a);
     if (lane < COST_SLOTS * 3u) cost_tbl[lane] = 0u;
-    uint32_t* pc = pixel_cache_of_lane<LDS>(a);
     uint32_t starve = 0;
     uint32_t pull_seq = 0;
 
@@ -1062,16 +1124,18 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (!active && rank < pool_left) {
                     const uint32_t q = pool_base + rank;
-                    const PixelCoord px = pixel_of(a, q >> 6, q & 63u);
+                    ColdArgs& ca = cold_args();
+                    const PixelCoord px = pixel_of(ca, q >> 6, q & 63u);
                     if (px.valid) {
                         DIAG(15);
-                        pixel_begin(a, cam, s, px.x, px.y, px.out_row);
-                        pixel_cache_begin(a, cam, s, pc);
+                        const CameraConsts cam = camera_consts(ca);
+                        pixel_begin(ca, cam, s, ls, px.x, px.y, px.out_row);
+                        pixel_cache_begin(a, ca, cam, s, ls);
                         s.meta = (pull_seq & (COST_SLOTS - 1u)) << 16;
                         if (have_samples) {
                             active = true;
                         } else {
-                            pixel_finish(a, s);  // 0 / 0 = NaN, as the shader would store
+                            pixel_finish(ca, s, ls);  // 0 / 0 = NaN, as the shader would store
                             if (a.tile_cost) tile_cost_add(a, cost_tbl, s);
                         }
                     }
@@ -1087,9 +1151,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
             continue;
         }
         if (active) {
-            if (path_step<LDS, STATS, TLAS>(a, cam, s, stack, pc, starve, n_segments, node_tests, tri_tests)) {
+            if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, node_tests, tri_tests)) {
                 DIAG(16);
-                pixel_finish(a, s);
+                pixel_finish(cold_args(), s, ls);
                 if (a.tile_cost) tile_cost_add(a, cost_tbl, s);
                 active = false;
             }
@@ -1112,7 +1176,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
 // ---------------------------------------------------------------------------
 template <bool LDS>
 __global__ void __launch_bounds__(BLOCK_THREADS) rt_debug_kernel(const RenderArgs a) {
-    uint32_t* stack = block_prologue<LDS>(a);
+    uint32_t* stack = stack_of(block_prologue<LDS>(a));
     const uint32_t tile = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (tile >= a.tiles_x * a.tiles_y) return;
     const PixelCoord px = pixel_of(a, tile, threadIdx.x & 63u);
@@ -1272,8 +1336,10 @@ size_t render_lds_bytes(const RenderArgs& a) {
     size_t stacks = ((size_t)(a.stack_entries ? a.stack_entries : 1u) * 128u + (size_t)a.tlas_entries * 64u) *
                     sizeof(uint32_t) * WAVES_PER_BLOCK;
     size_t cost_tables = 8u * 3u * sizeof(uint32_t) * WAVES_PER_BLOCK;
-    size_t cache = a.pixel_cache == 1u ? (size_t)PIXEL_CACHE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
-    return stacks + cost_tables + cache + (a.lds_scene ? a.lay.bytes : 0u);
+    size_t lane_state = (size_t)LANE_STATE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK;
+    size_t cache = a.pixel_cache == 1u ? (size_t)PIXEL_MEMO_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
+    // (= 4 x wave_region_dwords + the cost tables, see the LDS map)
+    return stacks + cost_tables + lane_state + cache + (a.lds_scene ? a.lay.bytes : 0u);
 }
 
 // Dynamic LDS above 64 KiB (deep-BVH stacks) has to be opted into per kernel.
