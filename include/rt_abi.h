@@ -252,8 +252,10 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  * "persistent_blocks" = grid size of variant 0 (256-thread workgroups);
  * "lds_scene" 0 = never stage the scene into LDS; "cull_roots" -1 auto / 0 / 1 =
  * results-preserving root-box culling of meshes in the mesh loop; "tlas" 0 = no top-level
- * trees over mesh root boxes (takes effect at the next rt_upload_scene); "pixel_cache" 0 = no
- * per-pixel memoisation of the primary ray and its hit; "vote_eighths" (0..8, default 6) and
+ * trees over mesh root boxes, "tlas_min" = smallest run of meshes that gets one (both take
+ * effect at the next rt_upload_scene); "pixel_cache" 0 = no per-pixel memoisation of the
+ * primary ray and its hit, 1 = memo in LDS when it fits (default), 2 = memo in global memory;
+ * "vote_eighths" (0..8, default 6) and
  * "vote_patience" (default 1) = the intersection vote of the render kernels; "tile_feedback" 0 = do not
  * reorder tiles by the previous frame's per-tile ray counts. */
 int rt_set_option(rt_handle* h, const char* name, int value);

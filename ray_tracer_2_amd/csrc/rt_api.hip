@@ -83,6 +83,7 @@ struct rt_handle {
     int pixel_cache_opt = 1;  // option "pixel_cache"
     int vote_eighths = 6, vote_patience = 1;  // options "vote_eighths", "vote_patience"
     int use_tlas = 1;  // option "tlas": 0 = every mesh is a single item (takes effect at the next upload)
+    int tlas_min = (int)TLAS_MIN_MESHES;  // option "tlas_min": smallest run of meshes that gets a top-level tree
     rt_camera_uniform camera{};
     int count_tests = 0;
     std::string err;
@@ -228,7 +229,7 @@ int rt_create(int device_ordinal, uint32_t max_width, uint32_t max_height, rt_ha
         hipDeviceProp_t prop;
         HIP_TRY(h, hipGetDeviceProperties(&prop, device_ordinal));
         // 4 waves per SIMD (the render kernels' register budget) = 4 workgroups of 4 waves per CU
-        h->persistent_blocks = (uint32_t)prop.multiProcessorCount * 4u;
+        h->persistent_blocks = (uint32_t)prop.multiProcessorCount * BLOCKS_PER_CU;
     }
     static const float lut[256] = {RT_SRGB_LUT_VALUES};
     HIP_TRY(h, hipMalloc((void**)&h->srgb_lut, sizeof(lut)));
@@ -337,10 +338,10 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 kind(cb, mn[n].right, bi, bc);
                 auto asf = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
                 WideRec w;
-                w.q[0] = make_float4(ca.aabb_min[0], ca.aabb_min[1], ca.aabb_min[2], asf(ai));
-                w.q[1] = make_float4(ca.aabb_max[0], ca.aabb_max[1], ca.aabb_max[2], asf(ac));
-                w.q[2] = make_float4(cb.aabb_min[0], cb.aabb_min[1], cb.aabb_min[2], asf(bi));
-                w.q[3] = make_float4(cb.aabb_max[0], cb.aabb_max[1], cb.aabb_max[2], asf(bc));
+                w.q[0] = make_float4(ca.aabb_min[0], ca.aabb_max[0], ca.aabb_min[1], ca.aabb_max[1]);
+                w.q[1] = make_float4(ca.aabb_min[2], ca.aabb_max[2], asf(ai), asf(ac));
+                w.q[2] = make_float4(cb.aabb_min[0], cb.aabb_max[0], cb.aabb_min[1], cb.aabb_max[1]);
+                w.q[3] = make_float4(cb.aabb_min[2], cb.aabb_max[2], asf(bi), asf(bc));
                 wide.push_back(w);
             }
         }
@@ -404,10 +405,10 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 build_tlas(ms, b0, mid, depth + 1, ai, ac, ba);
                 build_tlas(ms, mid, e0, depth + 1, bi, bc, bb);
                 WideRec w;
-                w.q[0] = make_float4(ba.lo[0], ba.lo[1], ba.lo[2], asf2(ai));
-                w.q[1] = make_float4(ba.hi[0], ba.hi[1], ba.hi[2], asf2(ac));
-                w.q[2] = make_float4(bb.lo[0], bb.lo[1], bb.lo[2], asf2(bi));
-                w.q[3] = make_float4(bb.hi[0], bb.hi[1], bb.hi[2], asf2(bc));
+                w.q[0] = make_float4(ba.lo[0], ba.hi[0], ba.lo[1], ba.hi[1]);
+                w.q[1] = make_float4(ba.lo[2], ba.hi[2], asf2(ai), asf2(ac));
+                w.q[2] = make_float4(bb.lo[0], bb.hi[0], bb.lo[1], bb.hi[1]);
+                w.q[3] = make_float4(bb.lo[2], bb.hi[2], asf2(bi), asf2(bc));
                 tlas[me] = w;
                 for (int k = 0; k < 3; ++k) {  // exact union (min/max are exact)
                     box.lo[k] = ba.lo[k] < bb.lo[k] ? ba.lo[k] : bb.lo[k];
@@ -423,7 +424,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             if (h->use_tlas)
                 for (uint32_t i = i0; i < i1; ++i)
                     if (root_box_ok(i)) grouped.push_back(i);
-            if (grouped.size() < TLAS_MIN_MESHES) grouped.clear();
+            if (grouped.size() < (size_t)h->tlas_min) grouped.clear();
             bool first = true;
             auto flag = [&]() { uint32_t f = first ? ITEM_NEW_XFORM : 0u; first = false; return f; };
             size_t g = 0;
@@ -472,8 +473,8 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             r[8] = make_float4(asf(flags), asf(root_idx[i]), asf(root_count[i]), asf(m.triangle_offset));
             r[9] = make_float4(asf(wide_base[i]), 0.0f, 0.0f, 0.0f);
             const rt_node& root = nodes[m.node_offset];
-            r[10] = make_float4(root.aabb_min[0], root.aabb_min[1], root.aabb_min[2], 0.0f);
-            r[11] = make_float4(root.aabb_max[0], root.aabb_max[1], root.aabb_max[2], 0.0f);
+            r[10] = make_float4(root.aabb_min[0], root.aabb_max[0], root.aabb_min[1], root.aabb_max[1]);
+            r[11] = make_float4(root.aabb_min[2], root.aabb_max[2], 0.0f, 0.0f);
             memcpy(blob.data() + (lay.mat_off + (size_t)i * MATERIAL_BYTES) / 16, &m.material, MATERIAL_BYTES);
         }
         if (!wide.empty()) memcpy(blob.data() + lay.wide_off / 16, wide.data(), wide.size() * sizeof(WideRec));
@@ -540,9 +541,10 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->tlas_entries = tlas_entries;
         h->has_tlas = has_tlas;
         h->n_items = (uint32_t)items.size();
-        // LDS residency: blob + the four waves' stacks within the per-workgroup budget
+        // LDS residency: blob + the four waves' stacks, cost tables and lane state within the
+        // per-workgroup budget (the primary-ray memo goes to LDS only if it still fits, see render_impl)
         uint64_t stacks = ((uint64_t)h->stack_entries * 128u + (uint64_t)h->tlas_entries * 64u) * sizeof(uint32_t) * WAVES_PER_BLOCK +
-                          8u * 3u * 4u * WAVES_PER_BLOCK + (uint64_t)(LANE_STATE_DWORDS + PIXEL_MEMO_DWORDS) * 64u * 4u * WAVES_PER_BLOCK;
+                          8u * 3u * 4u * WAVES_PER_BLOCK + (uint64_t)LANE_STATE_DWORDS * 64u * 4u * WAVES_PER_BLOCK;
         h->lds_scene = (uint64_t)lay.bytes + stacks <= LDS_BUDGET_BYTES;
         h->camera = scene->camera;
         h->have_scene = true;
@@ -603,9 +605,13 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         if (value < 0) return fail(h, RT_ERR_INVALID_ARGUMENT, "vote_patience must be >= 0");
         h->vote_patience = value;
     } else if (n == "pixel_cache") {
-        h->pixel_cache_opt = value ? 1 : 0;
+        if (value < 0 || value > 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "pixel_cache must be 0, 1 or 2 (memo in global memory)");
+        h->pixel_cache_opt = value;
     } else if (n == "tlas") {
         h->use_tlas = value ? 1 : 0;
+    } else if (n == "tlas_min") {
+        if (value < 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "tlas_min must be >= 2");
+        h->tlas_min = value;
     } else if (n == "cull_roots") {
         if (value < -1 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "cull_roots must be -1 (auto), 0 or 1");
         h->cull_roots = value;
@@ -680,18 +686,18 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.vote_patience = (uint32_t)h->vote_patience;
     a.pixel_cache = 0;
     a.pixel_cache_mem = nullptr;
-    if (h->pixel_cache_opt) {
+    if (h->pixel_cache_opt == 1) {
         a.pixel_cache = 1;
         if (render_lds_bytes(a) > LDS_BUDGET_BYTES) a.pixel_cache = 0;  // no room in LDS
     }
     a.persistent_blocks = h->persistent_blocks;
     {
-        // workgroups that fit a CU's 160 KiB of LDS (4 when the register budget is the limit)
+        // workgroups that fit a CU's 160 KiB of LDS (BLOCKS_PER_CU when the register budget is the limit)
         const size_t lds = render_lds_bytes(a);
-        uint32_t per_cu = lds ? (uint32_t)((160u * 1024u) / lds) : 4u;
-        if (per_cu > 4u) per_cu = 4u;
+        uint32_t per_cu = lds ? (uint32_t)((160u * 1024u) / lds) : BLOCKS_PER_CU;
+        if (per_cu > BLOCKS_PER_CU) per_cu = BLOCKS_PER_CU;
         if (per_cu < 1u) per_cu = 1u;
-        const uint32_t fit = (h->persistent_blocks / 4u) * per_cu;
+        const uint32_t fit = (h->persistent_blocks / BLOCKS_PER_CU) * per_cu;
         if (fit < a.persistent_blocks && fit > 0) a.persistent_blocks = fit;
     }
     if (h->pixel_cache_opt && a.pixel_cache == 0 && a.kernel_variant == 0 && params->debug_flag == 0) {

@@ -47,7 +47,7 @@ constexpr uint32_t TLAS_MIN_MESHES = 8;
 // Mesh record, 12 x 16 B:
 //   q0..q3  world_to_model columns   q4..q7  model_to_world columns
 //   q8 = (flags, root_idx, root_count, tri_base)   q9 = (wide_base, 0, 0, 0)
-//   q10 = (root aabb_min, 0)   q11 = (root aabb_max, 0)
+//   q10 = root (min.x, max.x, min.y, max.y)   q11 = root (min.z, max.z, 0, 0)
 // root_count > 0: the root is a leaf with triangles [root_idx, root_idx+count);
 // root_count == 0: root_idx is the mesh-local index of its wide record.
 constexpr uint32_t MESH_REC_BYTES = 192;
@@ -58,7 +58,8 @@ enum : uint32_t {
 };
 // Wide BVH record of one internal node (both children's boxes inline, so a
 // visit is one round trip instead of three dependent ones), 4 x 16 B:
-//   q0 = (a.min, a_idx) q1 = (a.max, a_count) q2 = (b.min, b_idx) q3 = (b.max, b_count)
+//   q0 = (a.min.x, a.max.x, a.min.y, a.max.y) q1 = (a.min.z, a.max.z, a_idx, a_count)
+//   q2, q3 = the same for child b   (min/max of an axis adjacent: one packed-f32 pair per axis)
 // child leaf: idx = first triangle (mesh-local), count > 0;
 // child internal: idx = mesh-local wide index, count = 0.
 constexpr uint32_t WIDE_REC_BYTES = 64;
@@ -73,8 +74,14 @@ constexpr uint32_t TRI_SHADE_BYTES = 64;
 constexpr uint32_t MATERIAL_BYTES = 96;
 constexpr uint32_t SPHERE_BYTES = 16;
 
-// LDS budget per 256-thread workgroup (4 workgroups per CU share 160 KiB).
-constexpr uint32_t LDS_BUDGET_BYTES = 40 * 1024;
+// Occupancy target: workgroups of 256 threads (one wave per SIMD) resident per CU = waves per
+// SIMD.  The render kernels are compiled for that register budget (512 / RT_MIN_WAVES VGPRs) and
+// the LDS budget per workgroup is the CU's 160 KiB divided by it.
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 4
+#endif
+constexpr uint32_t BLOCKS_PER_CU = RT_MIN_WAVES;
+constexpr uint32_t LDS_BUDGET_BYTES = 160 * 1024 / BLOCKS_PER_CU;
 constexpr uint32_t BLOCK_THREADS = 256;
 constexpr uint32_t WAVES_PER_BLOCK = BLOCK_THREADS / 64;
 // Per-lane state kept in LDS instead of registers (see path_step): the pixel's running sum

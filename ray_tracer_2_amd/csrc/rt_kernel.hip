@@ -42,9 +42,6 @@ namespace {
 #define DEV __device__ __forceinline__
 
 // waves per SIMD the render kernels are compiled for (register budget 512 / N)
-#ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 4
-#endif
 
 // Diagnostic build only (-DRT_DIAG=1, tools/diag.py): per-section wave visits
 // and active-lane sums, to price divergence.  Compiled out of the product.
@@ -169,6 +166,9 @@ extern __shared__ float4 lds_mem[];
 
 template <bool LDS>
 DEV float4 ld4(const RenderArgs& a, uint32_t byte_off) {
+    // every record of the blob is 16-byte aligned: lets neighbouring loads share one address
+    // register with immediate offsets instead of masking each address
+    __builtin_assume((byte_off & 15u) == 0u);
     if constexpr (LDS) {
         return lds_mem[byte_off >> 4];
     } else {
@@ -238,12 +238,17 @@ DEV void tri_test(f3 lo, f3 ld, float4 q0, float4 q1, float4 q2, bool cull, uint
     }
 }
 
-// wgsl:337-351
-DEV float aabb_dist(f3 lo, f3 inv, float4 bmin, float4 bmax, float t) {
-    float t1x = (bmin.x - lo.x) * inv.x, t1y = (bmin.y - lo.y) * inv.y, t1z = (bmin.z - lo.z) * inv.z;
-    float t2x = (bmax.x - lo.x) * inv.x, t2y = (bmax.y - lo.y) * inv.y, t2z = (bmax.z - lo.z) * inv.z;
-    float t_near = max_(max_(min_(t1x, t2x), min_(t1y, t2y)), min_(t1z, t2z));
-    float t_far = min_(min_(max_(t1x, t2x), max_(t1y, t2y)), max_(t1z, t2z));
+// wgsl:337-351 on a packed box record (rt_device.h): qa = (min.x, max.x, min.y, max.y),
+// qb = (min.z, max.z, idx, count).  Each axis' two slab distances are one packed subtract and
+// one packed multiply (v_pk_add_f32 / v_pk_mul_f32: two IEEE operations per instruction, the
+// same operations the shader's vector expressions perform per component).
+typedef float v2f __attribute__((ext_vector_type(2)));
+DEV float aabb_dist(f3 lo, f3 inv, float4 qa, float4 qb, float t) {
+    const v2f tx = (v2f{qa.x, qa.y} - lo.x) * inv.x;  // (t1.x, t2.x)
+    const v2f ty = (v2f{qa.z, qa.w} - lo.y) * inv.y;
+    const v2f tz = (v2f{qb.x, qb.y} - lo.z) * inv.z;
+    float t_near = max_(max_(min_(tx.x, tx.y), min_(ty.x, ty.y)), min_(tz.x, tz.y));
+    float t_far = min_(min_(max_(tx.x, tx.y), max_(ty.x, ty.y)), max_(tz.x, tz.y));
     bool did_hit = t_far >= t_near && t_near < t && t_far > 0.0f;
     return did_hit ? t_near : INF;
 }
@@ -299,12 +304,12 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
                 const bool left_closer = da < db;
                 const float near_d = left_closer ? da : db, far_d = left_closer ? db : da;
                 if (far_d < best.t) {
-                    stack[slot(stack_index)] = fbits(left_closer ? q2.w : q0.w);
+                    stack[slot(stack_index)] = fbits(left_closer ? q3.z : q1.z);
                     stack[slot(stack_index) + 64] = fbits(left_closer ? q3.w : q1.w);
                     stack_index += 1;
                 }
                 if (near_d < best.t) {
-                    stack[slot(stack_index)] = fbits(left_closer ? q0.w : q2.w);
+                    stack[slot(stack_index)] = fbits(left_closer ? q1.z : q3.z);
                     stack[slot(stack_index) + 64] = fbits(left_closer ? q1.w : q3.w);
                     stack_index += 1;
                 }
@@ -325,8 +330,8 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
             if (STATS) node_tests += 2;
             const bool left_closer = da < db;
             const float near_d = left_closer ? da : db, far_d = left_closer ? db : da;
-            const uint32_t near_i = fbits(left_closer ? q0.w : q2.w), near_c = fbits(left_closer ? q1.w : q3.w);
-            const uint32_t far_i = fbits(left_closer ? q2.w : q0.w), far_c = fbits(left_closer ? q3.w : q1.w);
+            const uint32_t near_i = fbits(left_closer ? q1.z : q3.z), near_c = fbits(left_closer ? q1.w : q3.w);
+            const uint32_t far_i = fbits(left_closer ? q3.z : q1.z), far_c = fbits(left_closer ? q3.w : q1.w);
             if (far_d < best.t) {
                 stack[sp * 128] = far_i;
                 stack[sp * 128 + 64] = far_c;
@@ -512,11 +517,11 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                     const bool hit_a = !cull_ok || aabb_dist(lo, inv, q0, q1, INF) < INF;
                     const bool hit_b = !cull_ok || aabb_dist(lo, inv, q2, q3, INF) < INF;
                     if (hit_b) {
-                        tstack[tsp * 64] = fbits(q2.w) | (fbits(q3.w) ? 0x80000000u : 0u);
+                        tstack[tsp * 64] = fbits(q3.z) | (fbits(q3.w) ? 0x80000000u : 0u);
                         ++tsp;
                     }
                     if (hit_a) {
-                        tstack[tsp * 64] = fbits(q0.w) | (fbits(q1.w) ? 0x80000000u : 0u);
+                        tstack[tsp * 64] = fbits(q1.z) | (fbits(q1.w) ? 0x80000000u : 0u);
                         ++tsp;
                     }
                 }

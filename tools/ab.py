@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 import ray_tracer_2_amd as rt  # noqa: E402
 
 ALIAS = {"variant": "kernel_variant", "blocks": "persistent_blocks", "lds": "lds_scene", "fb": "tile_feedback", "cull": "cull_roots", "pc": "pixel_cache", "ve": "vote_eighths", "vp": "vote_patience"}
-DEFAULTS = {"kernel_variant": -1, "lds_scene": 1, "tile_feedback": 1, "cull_roots": -1, "pixel_cache": 1, "vote_eighths": 6, "vote_patience": 1}
+UPLOAD_OPTS = {"tlas", "tlas_min"}
+DEFAULTS = {"tlas": 1, "tlas_min": 8, "kernel_variant": -1, "lds_scene": 1, "tile_feedback": 1, "cull_roots": -1, "pixel_cache": 1, "vote_eighths": 6, "vote_patience": 1}
 
 
 def main():
@@ -32,7 +33,7 @@ def main():
         configs.append((arg, opts))
     rounds, per = int(os.environ.get("AB_ROUNDS", 5)), int(os.environ.get("AB_FRAMES", 4))
     times = {name: [] for name, _ in configs}
-    base_waves = None
+    last_upload_opts = set()
     for r in range(rounds + 1):
         for name, opts in configs:
             for k, v in DEFAULTS.items():
@@ -42,6 +43,9 @@ def main():
                     pass  # older experimental library without this option
             for k, v in opts.items():
                 tr.set_option(k, v)
+            if len(UPLOAD_OPTS & (set(opts) | last_upload_opts)) > 0:  # these take effect at upload time
+                tr.update_buffers(arrays)
+            last_upload_opts = UPLOAD_OPTS & set(opts)
             tr.reset_timing()
             for f in range(per):
                 tr.render(rt.make_params(W, H, NB, SPP, skybox=1, frames=1 + f))
