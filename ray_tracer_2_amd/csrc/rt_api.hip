@@ -305,12 +305,14 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             // (Meshes may alias node ranges; records are built per mesh.)
             wide_base[i] = (uint32_t)wide.size();
             const rt_node* mn = nodes + m.node_offset;
+            // (child and root indices are absolute: triangle index into the scene's triangle
+            // array, wide-record index into the scene's record array)
             if (mn[0].count > 0) {
-                root_idx[i] = mn[0].first;
+                root_idx[i] = m.triangle_offset + mn[0].first;
                 root_count[i] = mn[0].count;
                 continue;
             }
-            root_idx[i] = 0;
+            root_idx[i] = wide_base[i];
             root_count[i] = 0;
             std::vector<uint32_t> order;  // original mesh-local indices of internal nodes, pre-order
             std::vector<uint32_t> st{0u};
@@ -326,10 +328,10 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 const rt_node &ca = mn[mn[n].left], &cb = mn[mn[n].right];
                 auto kind = [&](const rt_node& c, uint32_t local, uint32_t& idx, uint32_t& cnt) {
                     if (c.count > 0) {
-                        idx = c.first;
+                        idx = m.triangle_offset + c.first;
                         cnt = c.count;
                     } else {
-                        idx = wide_index[m.node_offset + local];
+                        idx = wide_base[i] + wide_index[m.node_offset + local];
                         cnt = 0;
                     }
                 };

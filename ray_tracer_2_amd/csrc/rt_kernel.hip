@@ -262,10 +262,10 @@ DEV float aabb_dist(f3 lo, f3 inv, float4 qa, float4 qb, float t) {
 // "while-while": a lane first descends through internal nodes until it holds a
 // leaf, then the wave tests leaf triangles together.
 template <bool LDS, bool STATS>
-DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_count, uint32_t tri_base,
-                       uint32_t wide_base, bool cull, bool deep, f3 lo, f3 ld, f3 inv, uint32_t* stack,
+DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_count, bool cull, bool deep, f3 lo,
+                       f3 ld, f3 inv, uint32_t* stack,
                        MeshBest& best, int& node_tests, int& tri_tests) {
-    const uint32_t tri0 = a.lay.tri_off + tri_base * TRI_ISECT_BYTES;
+    const uint32_t tri0 = a.lay.tri_off;  // (indices are absolute)
     if (root_count > 0) {
         // Root is a leaf: every lane tests the same triangles (uniform reads).
         if (STATS) tri_tests += (int)root_count;
@@ -275,7 +275,7 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
         }
         return;
     }
-    const uint32_t wide0 = a.lay.wide_off + wide_base * WIDE_REC_BYTES;
+    const uint32_t wide0 = a.lay.wide_off;
     if (deep) {
         // BVH of height >= 32: the shader's `array<u32,32>` stack can overflow, and what it
         // then does is defined by naga's Restrict policy (out-of-range indices are clamped to
@@ -417,14 +417,14 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
     f3 win_point{0, 0, 0};
     // closest-hit update of wgsl:383-391; equal distances go to the lower mesh index, which is
     // what the shader's in-order loop with its strict `<` yields
-    auto visit_mesh = [&](uint32_t i, float4 hdr, uint32_t wide_base) {
+    auto visit_mesh = [&](uint32_t i, float4 hdr) {
         const uint32_t mo = a.lay.mesh_off + i * MESH_REC_BYTES;
         const uint32_t flags = fbits(hdr.x);
         MeshBest b;
         b.t = INF;
         b.tri = 0xffffffffu;
         b.u = b.v = b.w = b.det = 0.0f;
-        traverse_mesh<LDS, STATS>(a, fbits(hdr.y), fbits(hdr.z), fbits(hdr.w), wide_base,
+        traverse_mesh<LDS, STATS>(a, fbits(hdr.y), fbits(hdr.z),
                                   (flags & DMESH_GLASS) == 0, (flags & DMESH_DEEP) != 0, lo, ld, inv, stack, b,
                                   node_tests, tri_tests);
         if (b.tri != 0xffffffffu) {
@@ -464,8 +464,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                           rtm::abs_(lo.x) < INF && rtm::abs_(lo.y) < INF && rtm::abs_(lo.z) < INF;
         }
         if constexpr (!TLAS) {
-            visit_mesh(ia, ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16),
-                       __builtin_amdgcn_readfirstlane(fbits(item.w)));
+            visit_mesh(ia, ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16));
         } else {
             // Many-mesh kernels: one traversal loop serves single meshes (a one-entry stack)
             // and top-level trees, so the mesh visit is instantiated once.
@@ -509,7 +508,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                     const uint32_t mo = a.lay.mesh_off + mi * MESH_REC_BYTES;
                     const float4 hdr = ld4<LDS>(a, mo + 128);
                     if (STATS) node_tests -= 2;  // counted above; traverse_mesh counts them again
-                    visit_mesh(mi, hdr, fbits(ld4<LDS>(a, mo + 144).x));
+                    visit_mesh(mi, hdr);
                 } else {
                     const uint32_t wo = a.lay.tlas_off + e * WIDE_REC_BYTES;
                     const float4 q0 = ld4<LDS>(a, wo), q1 = ld4<LDS>(a, wo + 16), q2 = ld4<LDS>(a, wo + 32),
@@ -540,8 +539,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         DIAG(11);
         if (object >= 0) {
             const uint32_t mo = a.lay.mesh_off + (uint32_t)object * MESH_REC_BYTES;
-            const uint32_t tri_base = fbits(ld4<LDS>(a, mo + 128).w);
-            const uint32_t so = a.lay.shade_off + (tri_base + win.tri) * TRI_SHADE_BYTES;
+            const uint32_t so = a.lay.shade_off + win.tri * TRI_SHADE_BYTES;
             const float4 s0 = ld4<LDS>(a, so), s1 = ld4<LDS>(a, so + 16), s2 = ld4<LDS>(a, so + 32),
                          s3 = ld4<LDS>(a, so + 48);
             f3 n1{s0.x, s0.y, s0.z}, n2{s1.x, s1.y, s1.z}, n3{s2.x, s2.y, s2.z};
