@@ -80,9 +80,11 @@ struct rt_handle {
     uint32_t n_meshes = 0, n_spheres = 0, n_textures = 0, n_nodes = 0, n_triangles = 0;
     uint32_t stack_entries = 1, tlas_entries = 1, n_items = 0;
     bool has_tlas = false;
+    bool has_forest = false;
     int pixel_cache_opt = 1;  // option "pixel_cache"
     int vote_eighths = 6, vote_patience = 1;  // options "vote_eighths", "vote_patience"
     int use_tlas = 1;  // option "tlas": 0 = every mesh is a single item (takes effect at the next upload)
+    int use_forest = 1;  // option "forest": 0 = no forest items (takes effect at the next upload)
     int tlas_min = (int)TLAS_MIN_MESHES;  // option "tlas_min": smallest run of meshes that gets a top-level tree
     rt_camera_uniform camera{};
     int count_tests = 0;
@@ -355,6 +357,8 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         struct Item { uint32_t kind, a, b, n; };
         std::vector<Item> items;
         std::vector<WideRec> tlas;
+        struct ForestEntry { float4 q[3]; };
+        std::vector<ForestEntry> forest_entries;
         uint32_t tlas_depth = 0;
         auto root_box_ok = [&](uint32_t i) {
             const rt_node* mn = nodes + meshes[i].node_offset;
@@ -419,6 +423,18 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 idx = me;
                 cnt = 0;
             };
+        // Forest items are walked by the few-mesh kernels only: none when the scene gets a top-level
+        // tree anywhere or has enough meshes for automatic root-box culling (many-mesh kernels).
+        bool any_tlas = false;
+        if (h->use_tlas)
+            for (uint32_t i0 = 0; i0 < n_meshes;) {
+                uint32_t i1 = i0 + 1, ok = 0;
+                while (i1 < n_meshes && memcmp(meshes[i1].world_to_model, meshes[i0].world_to_model, 64) == 0) ++i1;
+                for (uint32_t i = i0; i < i1; ++i) ok += root_box_ok(i) ? 1u : 0u;
+                if (ok >= (uint32_t)h->tlas_min) any_tlas = true;
+                i0 = i1;
+            }
+        const bool allow_forest = h->use_forest && !any_tlas && n_meshes < 16;
         for (uint32_t i0 = 0; i0 < n_meshes;) {
             uint32_t i1 = i0 + 1;
             while (i1 < n_meshes && memcmp(meshes[i1].world_to_model, meshes[i0].world_to_model, 64) == 0) ++i1;
@@ -427,12 +443,40 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 for (uint32_t i = i0; i < i1; ++i)
                     if (root_box_ok(i)) grouped.push_back(i);
             if (grouped.size() < (size_t)h->tlas_min) grouped.clear();
+            // the other meshes of the run with an internal, non-deep root (and the run's
+            // model_to_world as well) form a forest when there are at least two of them
+            std::vector<uint32_t> forest;
+            if (allow_forest) {
+                size_t g = 0;
+                for (uint32_t i = i0; i < i1; ++i) {
+                    if (g < grouped.size() && grouped[g] == i) { ++g; continue; }
+                    if (root_count[i] == 0 && !deep[i] && memcmp(meshes[i].model_to_world, meshes[i0].model_to_world, 64) == 0)
+                        forest.push_back(i);
+                }
+                if (forest.size() < 2) forest.clear();
+            }
             bool first = true;
             auto flag = [&]() { uint32_t f = first ? ITEM_NEW_XFORM : 0u; first = false; return f; };
-            size_t g = 0;
+            size_t g = 0, fo = 0;
             for (uint32_t i = i0; i < i1; ++i) {
                 if (g < grouped.size() && grouped[g] == i) { ++g; continue; }
+                if (fo < forest.size() && forest[fo] == i) { ++fo; continue; }
                 items.push_back(Item{flag(), i, i0, 1});
+            }
+            for (size_t f0 = 0; f0 < forest.size(); f0 += FOREST_MAX_MEMBERS) {
+                const size_t f1 = std::min(forest.size(), f0 + (size_t)FOREST_MAX_MEMBERS);
+                items.push_back(Item{ITEM_FOREST | flag(), (uint32_t)forest_entries.size(), i0, (uint32_t)(f1 - f0)});
+                for (size_t f = f0; f < f1; ++f) {
+                    const uint32_t i = forest[f];
+                    const rt_node& r = nodes[meshes[i].node_offset];
+                    ForestEntry e;
+                    uint32_t fl = (meshes[i].material.flag == RT_MATERIAL_GLASS ? DMESH_GLASS : 0u) |
+                                  (root_box_ok(i) ? FOREST_CULLABLE : 0u);
+                    e.q[0] = make_float4(asf2(root_idx[i]), asf2(i), asf2(fl), 0.0f);
+                    e.q[1] = make_float4(r.aabb_min[0], r.aabb_max[0], r.aabb_min[1], r.aabb_max[1]);
+                    e.q[2] = make_float4(r.aabb_min[2], r.aabb_max[2], 0.0f, 0.0f);
+                    forest_entries.push_back(e);
+                }
             }
             if (!grouped.empty()) {
                 std::vector<uint32_t> ms = grouped;
@@ -459,6 +503,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         lay.sphere_off = (uint32_t)off; off += (uint64_t)n_spheres * SPHERE_BYTES;
         lay.item_off = (uint32_t)off;   off += (uint64_t)items.size() * ITEM_BYTES;
         lay.tlas_off = (uint32_t)off;   off += (uint64_t)tlas.size() * WIDE_REC_BYTES;
+        lay.forest_off = (uint32_t)off; off += (uint64_t)forest_entries.size() * FOREST_ENTRY_BYTES;
         if (off == 0) off = 16;
         if (off > 0xfffffff0ull) return fail(h, RT_ERR_CAPACITY, "scene larger than 4 GiB");
         lay.bytes = (uint32_t)off;
@@ -481,9 +526,11 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         }
         if (!wide.empty()) memcpy(blob.data() + lay.wide_off / 16, wide.data(), wide.size() * sizeof(WideRec));
         if (!tlas.empty()) memcpy(blob.data() + lay.tlas_off / 16, tlas.data(), tlas.size() * sizeof(WideRec));
+        if (!forest_entries.empty())
+            memcpy(blob.data() + lay.forest_off / 16, forest_entries.data(), forest_entries.size() * sizeof(ForestEntry));
         for (size_t k = 0; k < items.size(); ++k) {
             const Item& it = items[k];
-            const bool single = (it.kind & ITEM_TLAS) == 0;
+            const bool single = (it.kind & (ITEM_TLAS | ITEM_FOREST)) == 0;
             blob[lay.item_off / 16 + 2 * k] = make_float4(asf(it.kind), asf(it.a), asf(it.b), asf(single ? wide_base[it.a] : it.n));
             if (single) blob[lay.item_off / 16 + 2 * k + 1] = blob[(lay.mesh_off + (size_t)it.a * MESH_REC_BYTES) / 16 + 8];
         }
@@ -542,6 +589,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->stack_entries = max_height ? max_height : 1;
         h->tlas_entries = tlas_entries;
         h->has_tlas = has_tlas;
+        h->has_forest = !forest_entries.empty();
         h->n_items = (uint32_t)items.size();
         // LDS residency: blob + the four waves' stacks, cost tables and lane state within the
         // per-workgroup budget (the primary-ray memo goes to LDS only if it still fits, see render_impl)
@@ -611,6 +659,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         h->pixel_cache_opt = value;
     } else if (n == "tlas") {
         h->use_tlas = value ? 1 : 0;
+    } else if (n == "forest") {
+        h->use_forest = value ? 1 : 0;
     } else if (n == "tlas_min") {
         if (value < 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "tlas_min must be >= 2");
         h->tlas_min = value;
@@ -660,7 +710,8 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.lay = h->lay;
     a.lds_scene = (h->lds_scene && !h->force_global) ? 1u : 0u;
     a.cull_roots = (h->roots_are_unions && (h->cull_roots == 1 || (h->cull_roots < 0 && h->n_meshes >= 16))) ? 1u : 0u;
-    a.many_mesh = (h->has_tlas || a.cull_roots) ? 1u : 0u;
+    a.many_mesh = (h->has_tlas || (a.cull_roots && !h->has_forest)) ? 1u : 0u;
+    a.forest_cull = h->cull_roots != 0 ? 1u : 0u;
     // the per-lane primary-ray cache is used when it still leaves room for 4 workgroups per CU
     a.textures = h->textures;
     a.srgb_lut = h->srgb_lut;

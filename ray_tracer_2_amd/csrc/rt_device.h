@@ -26,8 +26,9 @@ struct SceneLayout {
     uint32_t sphere_off;  // 16 B (centre, radius) per sphere
     uint32_t item_off;    // ITEM_BYTES per item of the mesh loop
     uint32_t tlas_off;    // WIDE_REC_BYTES per node of the top-level trees over mesh root boxes
+    uint32_t forest_off;  // FOREST_ENTRY_BYTES per member of the forest items
     uint32_t bytes;       // total, multiple of 16
-    uint32_t _pad[3];
+    uint32_t _pad[2];
 };
 
 // The mesh loop (wgsl:369) runs over items.  An item is one mesh, or a top-level tree
@@ -40,8 +41,17 @@ struct SceneLayout {
 //        TLAS: a = root node index, c = number of meshes below it
 //   q1 = single mesh: a copy of the mesh record's q8 (flags, root_idx, root_count, tri_base), so
 //        that a mesh visit needs no dependent load.
+//   forest (ITEM_FOREST): a = first member entry, c = number of members (<= 32): meshes with an
+//        internal, non-deep root that share both matrices; each lane walks the members whose root
+//        box it hits one after the other, independently of the other lanes (traverse_forest).
 constexpr uint32_t ITEM_BYTES = 32;
-enum : uint32_t { ITEM_TLAS = 1u, ITEM_NEW_XFORM = 2u };
+enum : uint32_t { ITEM_TLAS = 1u, ITEM_NEW_XFORM = 2u, ITEM_FOREST = 4u };
+// Forest member entry, 3 x 16 B: q0 = (root wide index, mesh index, flags, 0), q1/q2 = the root's
+// packed box (as in a wide record).  flags: DMESH_GLASS, FOREST_CULLABLE = the root box provably
+// contains the boxes of the root's children (so missing it means missing the mesh).
+constexpr uint32_t FOREST_ENTRY_BYTES = 48;
+constexpr uint32_t FOREST_MAX_MEMBERS = 32;
+constexpr uint32_t FOREST_CULLABLE = 0x100u;
 constexpr uint32_t TLAS_MIN_MESHES = 8;
 
 // Mesh record, 12 x 16 B:
@@ -133,6 +143,7 @@ struct RenderArgs {
     uint32_t kernel_variant;    // 0 = persistent waves + lane refill, 1 = one wave per tile
     uint32_t persistent_blocks; // grid size of the persistent kernel
     uint32_t lds_scene;         // 1 => the blob is staged into LDS
+    uint32_t forest_cull;       // 1 => forest members are skipped when the ray misses their root box
     uint32_t cull_roots;        // 1 => skip a mesh with an internal root when the ray misses the root box
 };
 

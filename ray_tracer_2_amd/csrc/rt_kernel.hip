@@ -363,6 +363,103 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
     }
 }
 
+// A forest item (rt_device.h): meshes with an internal root that share one local space.  The
+// shader visits them one after the other with all lanes in step; here every lane first marks
+// the members whose root box its ray can hit, then walks ITS members back to back, so lanes
+// busy in different meshes share the node-visit and triangle passes instead of taking turns.
+// Per lane and per mesh the sequence of box and triangle tests is exactly traverse_mesh's;
+// meshes are independent of each other (each starts from an infinite best distance,
+// wgsl:292-296) and the caller's closest-hit update is order-free, so the result is the same.
+// Skipping a member whose root box is missed is the monotonicity argument of intersect_scene
+// (FOREST_CULLABLE members only, finite ray only).
+template <bool LDS, bool STATS, class Accept>
+DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_members, f3 lo, f3 ld, f3 inv,
+                         uint32_t* stack, Accept&& accept, int& node_tests, int& tri_tests) {
+    const bool finite_ray = rtm::abs_(inv.x) < INF && rtm::abs_(inv.y) < INF && rtm::abs_(inv.z) < INF &&
+                            rtm::abs_(lo.x) < INF && rtm::abs_(lo.y) < INF && rtm::abs_(lo.z) < INF;
+    const uint32_t e0 = a.lay.forest_off + entry0 * FOREST_ENTRY_BYTES;
+    uint32_t todo = 0;  // bit j: member j still to be traversed by this lane
+    for (uint32_t j = 0; j < n_members; ++j) {
+        const uint32_t eo = e0 + j * FOREST_ENTRY_BYTES;
+        const uint32_t flags = fbits(ld4<LDS>(a, eo).z);
+        bool may_hit = true;
+        if ((flags & FOREST_CULLABLE) != 0u && a.forest_cull != 0u)
+            may_hit = !finite_ray || aabb_dist(lo, inv, ld4<LDS>(a, eo + 16), ld4<LDS>(a, eo + 32), INF) < INF;
+        if (may_hit) todo |= 1u << j;
+        else if (STATS) node_tests += 2;  // the shader's two root-level tests (wgsl:322)
+    }
+    const uint32_t tri0 = a.lay.tri_off, wide0 = a.lay.wide_off;
+    uint32_t cur = 0, cur_count = 0, sp = 0, mesh = 0;
+    bool have = false, cull = false;
+    MeshBest b;
+    b.t = INF;
+    b.tri = 0xffffffffu;
+    b.u = b.v = b.w = b.det = 0.0f;
+    for (;;) {
+        if (!have) {
+            if (b.tri != 0xffffffffu) {  // the mesh just left had a hit
+                accept(mesh, b);
+                b.tri = 0xffffffffu;
+            }
+            if (todo != 0u) {
+                const uint32_t j = (uint32_t)__builtin_ctz(todo);
+                todo &= todo - 1u;
+                const float4 e = ld4<LDS>(a, e0 + j * FOREST_ENTRY_BYTES);
+                cur = fbits(e.x);
+                cur_count = 0;
+                mesh = fbits(e.y);
+                cull = (fbits(e.z) & DMESH_GLASS) == 0u;
+                b.t = INF;
+                sp = 0;
+                have = true;
+            }
+        }
+        if (__ballot(have) == 0ull) break;
+        while (have && cur_count == 0) {  // descend to the next leaf
+            DIAG(7);
+            const uint32_t wo = wide0 + cur * WIDE_REC_BYTES;
+            const float4 q0 = ld4<LDS>(a, wo), q1 = ld4<LDS>(a, wo + 16), q2 = ld4<LDS>(a, wo + 32),
+                         q3 = ld4<LDS>(a, wo + 48);
+            float da = aabb_dist(lo, inv, q0, q1, b.t);
+            float db = aabb_dist(lo, inv, q2, q3, b.t);
+            if (STATS) node_tests += 2;
+            const bool left_closer = da < db;
+            const float near_d = left_closer ? da : db, far_d = left_closer ? db : da;
+            const uint32_t near_i = fbits(left_closer ? q1.z : q3.z), near_c = fbits(left_closer ? q1.w : q3.w);
+            const uint32_t far_i = fbits(left_closer ? q3.z : q1.z), far_c = fbits(left_closer ? q3.w : q1.w);
+            if (far_d < b.t) {
+                stack[sp * 128] = far_i;
+                stack[sp * 128 + 64] = far_c;
+                ++sp;
+            }
+            if (near_d < b.t) {
+                cur = near_i;
+                cur_count = near_c;
+            } else if (sp == 0) {
+                have = false;
+            } else {
+                --sp;
+                cur = stack[sp * 128];
+                cur_count = stack[sp * 128 + 64];
+            }
+        }
+        if (have) {  // a leaf
+            if (STATS) tri_tests += (int)cur_count;
+            for (uint32_t j = 0; j < cur_count; ++j) {
+                const uint32_t t = tri0 + (cur + j) * TRI_ISECT_BYTES;
+                tri_test<8>(lo, ld, ld4<LDS>(a, t), ld4<LDS>(a, t + 16), ld4<LDS>(a, t + 32), cull, cur + j, b);
+            }
+            if (sp == 0) {
+                have = false;
+            } else {
+                --sp;
+                cur = stack[sp * 128];
+                cur_count = stack[sp * 128 + 64];
+            }
+        }
+    }
+}
+
 struct Hit {
     bool hit;
     float dst;
@@ -417,8 +514,24 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
     f3 win_point{0, 0, 0};
     // closest-hit update of wgsl:383-391; equal distances go to the lower mesh index, which is
     // what the shader's in-order loop with its strict `<` yields
-    auto visit_mesh = [&](uint32_t i, float4 hdr) {
+    auto accept_mesh_hit = [&](uint32_t i, const MeshBest& b) {
+        DIAG(10);
         const uint32_t mo = a.lay.mesh_off + i * MESH_REC_BYTES;
+        const float4 c0 = ld4<LDS>(a, mo + 64), c1 = ld4<LDS>(a, mo + 80), c2 = ld4<LDS>(a, mo + 96),
+                     c3 = ld4<LDS>(a, mo + 112);
+        f3 lhp = lo + ld * b.t;
+        f3 whp = mat_cols_xyz(c0, c1, c2, c3, lhp, 1.0f);
+        f3 dv = ro - whp;
+        float wdst = rtm::sqrt_(dot3(dv, dv));
+        if (wdst < closest || (wdst == closest && any && object >= 0 && (int)i < object)) {
+            closest = wdst;
+            any = true;
+            object = (int)i;
+            win = b;
+            win_point = whp;
+        }
+    };
+    auto visit_mesh = [&](uint32_t i, float4 hdr) {
         const uint32_t flags = fbits(hdr.x);
         MeshBest b;
         b.t = INF;
@@ -427,22 +540,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         traverse_mesh<LDS, STATS>(a, fbits(hdr.y), fbits(hdr.z),
                                   (flags & DMESH_GLASS) == 0, (flags & DMESH_DEEP) != 0, lo, ld, inv, stack, b,
                                   node_tests, tri_tests);
-        if (b.tri != 0xffffffffu) {
-            DIAG(10);
-            const float4 c0 = ld4<LDS>(a, mo + 64), c1 = ld4<LDS>(a, mo + 80), c2 = ld4<LDS>(a, mo + 96),
-                         c3 = ld4<LDS>(a, mo + 112);
-            f3 lhp = lo + ld * b.t;
-            f3 whp = mat_cols_xyz(c0, c1, c2, c3, lhp, 1.0f);
-            f3 dv = ro - whp;
-            float wdst = rtm::sqrt_(dot3(dv, dv));
-            if (wdst < closest || (wdst == closest && any && object >= 0 && (int)i < object)) {
-                closest = wdst;
-                any = true;
-                object = (int)i;
-                win = b;
-                win_point = whp;
-            }
-        }
+        if (b.tri != 0xffffffffu) accept_mesh_hit(i, b);
     };
     for (uint32_t it = 0; it < a.n_items; ++it) {
         const float4 item = ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES);
@@ -462,6 +560,11 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             if constexpr (TLAS)
                 cull_ok = rtm::abs_(inv.x) < INF && rtm::abs_(inv.y) < INF && rtm::abs_(inv.z) < INF &&
                           rtm::abs_(lo.x) < INF && rtm::abs_(lo.y) < INF && rtm::abs_(lo.z) < INF;
+        }
+        if constexpr (!TLAS) if (kind & ITEM_FOREST) {
+            traverse_forest<LDS, STATS>(a, ia, __builtin_amdgcn_readfirstlane(fbits(item.w)), lo, ld, inv, stack,
+                                        accept_mesh_hit, node_tests, tri_tests);
+            continue;
         }
         if constexpr (!TLAS) {
             visit_mesh(ia, ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16));
@@ -655,8 +758,11 @@ DEV void store_texel(const A& a, uint32_t x, uint32_t out_row, f4 cur) {
 //   [lane state, LANE_STATE_DWORDS x 64] [BVH stack, stack_entries x 2 x 64] [TLAS stack, tlas_entries x 64]
 // Everything is addressed from ONE per-lane pointer (the lane-state base) with immediate
 // offsets, so the whole map costs a single VGPR.
+// (kernels that read the scene from global memory tend to have deep stacks and an LDS-bound
+// occupancy: they keep the pixel sum in registers instead)
+DEV uint32_t lane_state_dwords(const RenderArgs& a) { return a.lds_scene ? LANE_STATE_DWORDS : 0u; }
 DEV uint32_t wave_region_dwords(const RenderArgs& a) {
-    return (a.pixel_cache == 1u ? PIXEL_MEMO_DWORDS * 64u : 0u) + LANE_STATE_DWORDS * 64u +
+    return (a.pixel_cache == 1u ? PIXEL_MEMO_DWORDS * 64u : 0u) + lane_state_dwords(a) * 64u +
            (a.stack_entries ? a.stack_entries : 1u) * 128u + a.tlas_entries * 64u;
 }
 
@@ -675,7 +781,8 @@ DEV uint32_t* block_prologue(const RenderArgs& a) {
     return reinterpret_cast<uint32_t*>(lds_mem + base) + wave * wave_region_dwords(a) +
            (a.pixel_cache == 1u ? PIXEL_MEMO_DWORDS * 64u : 0u) + lane;
 }
-DEV uint32_t* stack_of(uint32_t* lane_base) { return lane_base + LANE_STATE_DWORDS * 64u; }
+template <bool LDS>
+DEV uint32_t* stack_of(uint32_t* lane_base) { return lane_base + (LDS ? LANE_STATE_DWORDS * 64u : 0u); }
 
 // The persistent kernel's per-wave tile-cost tables follow the wave regions.
 template <bool LDS>
@@ -713,7 +820,8 @@ struct PixelState {
     uint32_t rng;          // wgsl:475, one stream per pixel
     int32_t j;             // sample index (wgsl:487)
     // current path (wgsl:398-471); `total` (wgsl:486) lives in the lane's LDS state region
-    // (LANE_STATE_DWORDS), not in registers
+    // (LANE_STATE_DWORDS) in the LDS-scene kernels, in registers otherwise
+    f4 total;
     f3 ro, rd;
     f4 T, light;
     int32_t seg;
@@ -737,7 +845,7 @@ DEV uint32_t frame_row_of(const A& a, uint32_t out_row) {
 }
 
 // wgsl:475 for pixel (x, y) of the full frame
-template <class A>
+template <bool LDS, class A>
 DEV void pixel_begin(const A& a, const CameraConsts& c, PixelState& s, uint32_t* ls, uint32_t x,
                      uint32_t y, uint32_t out_row) {
     const float fx = (float)x, fy = (float)y;
@@ -746,7 +854,10 @@ DEV void pixel_begin(const A& a, const CameraConsts& c, PixelState& s, uint32_t*
     s.rng = (uint32_t)(fy * c.sx + fx) + absf * 719393u;
     s.x = x;
     s.out_row = out_row;
-    ls[0] = 0u; ls[64] = 0u; ls[128] = 0u; ls[192] = 0u;  // total = 0
+    if constexpr (LDS) {
+        ls[0] = 0u; ls[64] = 0u; ls[128] = 0u; ls[192] = 0u;  // total = 0
+    }
+    s.total = f4{0, 0, 0, 0};
     s.j = 0;
     s.fresh = true;
     s.seg = 0;
@@ -822,7 +933,7 @@ template <bool LDS, bool STATS, bool TLAS>
 DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
                    int& node_tests, int& tri_tests) {
     const int32_t nb = a.params.number_of_bounces;
-    uint32_t* stack = stack_of(ls);
+    uint32_t* stack = stack_of<LDS>(ls);
     // Primary-ray memo.  With defocus_strength = diverge_strength = +0 (the default camera) the
     // camera jitter is +-0, and unless a component of the camera origin or of the pixel's focus
     // point is -0 the sums `origin + right*j.x + up*j.y` do not depend on those signs: every
@@ -981,10 +1092,14 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
         }
     }
     if (end_path) {  // wgsl:496
-        ls[0] = __float_as_uint(__uint_as_float(ls[0]) + s.light.x);  // total += incoming_light
-        ls[64] = __float_as_uint(__uint_as_float(ls[64]) + s.light.y);
-        ls[128] = __float_as_uint(__uint_as_float(ls[128]) + s.light.z);
-        ls[192] = __float_as_uint(__uint_as_float(ls[192]) + s.light.w);
+        if constexpr (LDS) {
+            ls[0] = __float_as_uint(__uint_as_float(ls[0]) + s.light.x);  // total += incoming_light
+            ls[64] = __float_as_uint(__uint_as_float(ls[64]) + s.light.y);
+            ls[128] = __float_as_uint(__uint_as_float(ls[128]) + s.light.z);
+            ls[192] = __float_as_uint(__uint_as_float(ls[192]) + s.light.w);
+        } else {
+            s.total = s.total + s.light;
+        }
         s.j += 1;
         s.fresh = true;
         return s.j >= a.params.rays_per_pixel;
@@ -993,10 +1108,12 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
 }
 
 // wgsl:498 + 154-161
-template <class A>
+template <bool LDS, class A>
 DEV void pixel_finish(const A& a, const PixelState& s, const uint32_t* ls) {
     float n = (float)a.params.rays_per_pixel;
-    const f4 total{__uint_as_float(ls[0]), __uint_as_float(ls[64]), __uint_as_float(ls[128]), __uint_as_float(ls[192])};
+    f4 total = s.total;
+    if constexpr (LDS)
+        total = f4{__uint_as_float(ls[0]), __uint_as_float(ls[64]), __uint_as_float(ls[128]), __uint_as_float(ls[192])};
     store_texel(a, s.x, s.out_row, f4{total.x / n, total.y / n, total.z / n, total.w / n});
 }
 
@@ -1058,7 +1175,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     const PixelCoord px = pixel_of(a, tile, threadIdx.x & 63u);
     const bool valid = tile_ok && px.valid;
     PixelState s;
-    pixel_begin(a, cam, s, ls, px.x, px.y, px.out_row);
+    pixel_begin<LDS>(a, cam, s, ls, px.x, px.y, px.out_row);
     pixel_cache_begin(a, a, cam, s, ls);
     uint32_t starve = 0;
     bool active = valid && a.params.rays_per_pixel > 0;
@@ -1067,7 +1184,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     while (active) {
         if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, node_tests, tri_tests)) active = false;
     }
-    if (valid) pixel_finish(a, s, ls);
+    if (valid) pixel_finish<LDS>(a, s, ls);
     if (a.tile_cost && tile_ok) {  // one store per wave: the tile's rays
         uint32_t sum = n_segments;
         for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
@@ -1095,7 +1212,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
     uint32_t pool_base = 0, pool_left = 0;  // wave-uniform: pixels left in the current tile
     bool exhausted = false;
     PixelState s;
-    pixel_begin(a, camera_consts(a), s, ls, 0, 0, 0);
+    pixel_begin<LDS>(a, camera_consts(a), s, ls, 0, 0, 0);
     bool active = false;
     uint32_t n_segments = 0;
     int node_tests = 0, tri_tests = 0;
@@ -1132,13 +1249,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                     if (px.valid) {
                         DIAG(15);
                         const CameraConsts cam = camera_consts(ca);
-                        pixel_begin(ca, cam, s, ls, px.x, px.y, px.out_row);
+                        pixel_begin<LDS>(ca, cam, s, ls, px.x, px.y, px.out_row);
                         pixel_cache_begin(a, ca, cam, s, ls);
                         s.meta = (pull_seq & (COST_SLOTS - 1u)) << 16;
                         if (have_samples) {
                             active = true;
                         } else {
-                            pixel_finish(ca, s, ls);  // 0 / 0 = NaN, as the shader would store
+                            pixel_finish<LDS>(ca, s, ls);  // 0 / 0 = NaN, as the shader would store
                             if (a.tile_cost) tile_cost_add(a, cost_tbl, s);
                         }
                     }
@@ -1156,7 +1273,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         if (active) {
             if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, node_tests, tri_tests)) {
                 DIAG(16);
-                pixel_finish(cold_args(), s, ls);
+                pixel_finish<LDS>(cold_args(), s, ls);
                 if (a.tile_cost) tile_cost_add(a, cost_tbl, s);
                 active = false;
             }
@@ -1177,9 +1294,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
 // ---------------------------------------------------------------------------
 // wgsl debug_trace (wgsl:502-573): one primary ray, no RNG.
 // ---------------------------------------------------------------------------
-template <bool LDS>
+template <bool LDS, bool TLAS>
 __global__ void __launch_bounds__(BLOCK_THREADS) rt_debug_kernel(const RenderArgs a) {
-    uint32_t* stack = stack_of(block_prologue<LDS>(a));
+    uint32_t* stack = stack_of<LDS>(block_prologue<LDS>(a));
     const uint32_t tile = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (tile >= a.tiles_x * a.tiles_y) return;
     const PixelCoord px = pixel_of(a, tile, threadIdx.x & 63u);
@@ -1194,7 +1311,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rt_debug_kernel(const RenderArg
     const f3 focus_point = mat_xyz(c2w, local_focus, 1.0f);
     f3 rd = normalize3(focus_point - cam_origin);
     int s0 = 0, s1 = 0;
-    Hit hit = intersect_scene<LDS, true, true>(a, cam_origin, rd, stack, s0, s1);
+    Hit hit = intersect_scene<LDS, true, TLAS>(a, cam_origin, rd, stack, s0, s1);
     const float scale = (float)a.params.debug_scale;
     f4 out{1.0f, 0.0f, 1.0f, 1.0f};
     switch (a.params.debug_flag) {
@@ -1339,7 +1456,7 @@ size_t render_lds_bytes(const RenderArgs& a) {
     size_t stacks = ((size_t)(a.stack_entries ? a.stack_entries : 1u) * 128u + (size_t)a.tlas_entries * 64u) *
                     sizeof(uint32_t) * WAVES_PER_BLOCK;
     size_t cost_tables = 8u * 3u * sizeof(uint32_t) * WAVES_PER_BLOCK;
-    size_t lane_state = (size_t)LANE_STATE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK;
+    size_t lane_state = a.lds_scene ? (size_t)LANE_STATE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
     size_t cache = a.pixel_cache == 1u ? (size_t)PIXEL_MEMO_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
     // (= 4 x wave_region_dwords + the cost tables, see the LDS map)
     return stacks + cost_tables + lane_state + cache + (a.lds_scene ? a.lay.bytes : 0u);
@@ -1357,7 +1474,7 @@ template <bool LDS, bool TLAS>
 static void launch_variant(const RenderArgs& a, uint32_t ntiles, size_t lds, hipStream_t stream) {
     const uint32_t tile_blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (a.params.debug_flag != 0) {
-        launch_k(rt_debug_kernel<LDS>, tile_blocks, lds, stream, a);
+        launch_k(rt_debug_kernel<LDS, TLAS>, tile_blocks, lds, stream, a);
     } else if (a.kernel_variant == 1) {
         if (a.count_tests) launch_k(rt_render_tiles_kernel<LDS, true, TLAS>, tile_blocks, lds, stream, a);
         else launch_k(rt_render_tiles_kernel<LDS, false, TLAS>, tile_blocks, lds, stream, a);

@@ -23,6 +23,10 @@ def main():
     arrays = rt.SceneArrays.from_scene(sc)
     W, H = 1920, 1080
     tr = rt.RayTracer(0, W, H)
+    for kv in os.environ.get("BS_OPTS", "").split(","):   # e.g. BS_OPTS=forest=0,tlas=0 (upload-time options too)
+        if kv:
+            k, v = kv.split("=")
+            tr.set_option(k, int(v))
     tr.load_scene(arrays)
     print(f"triangles {arrays.triangles.shape[0]}, nodes {arrays.nodes.shape[0]}, meshes {arrays.meshes.shape[0]}")
     for variant in (0, 1):
