@@ -25,7 +25,7 @@ hipError_t launch_tile_order(const uint32_t* cost, uint32_t n_tiles, uint32_t ma
                              hipStream_t stream);
 hipError_t launch_assemble(const float4* gathered, float4* image, uint32_t width, uint32_t height,
                            uint32_t world, unsigned long long pad_texels, hipStream_t stream);
-#if defined(RT_DIAG)
+#if defined(RT_DIAG) || defined(RT_DIAGT)
 hipError_t diag_read(unsigned long long* out, bool reset);
 #endif
 #if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
@@ -990,7 +990,7 @@ int rt_diag_wave_times(rt_handle* h, unsigned long long* out) {
     return RT_OK;
 }
 #endif
-#if defined(RT_DIAG)
+#if defined(RT_DIAG) || defined(RT_DIAGT)
 int rt_diag_read(rt_handle* h, unsigned long long* out64, int reset) {
     if (!h || !out64) return RT_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));

@@ -48,8 +48,25 @@ namespace {
 #if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
 __device__ unsigned long long g_wave_times[2 * 8192];  // (start, end) s_memrealtime per persistent wave
 #endif
-#if defined(RT_DIAG)
+#if defined(RT_DIAG) || defined(RT_DIAGT)
 __device__ unsigned long long g_diag[64];
+#endif
+#if defined(RT_DIAGT)
+// Timing build (-DRT_DIAGT=1, tools/diag.py --time): wave-cycles per code section.
+// (accumulated per wave in LDS, flushed once at the end of the persistent kernel: global atomics
+// per section would serialise at L2 and distort everything)
+__shared__ unsigned long long g_tacc[4][24];
+#define TIC(v) const unsigned long long v = __builtin_readcyclecounter()
+#define TOC(v, id)                                                                                  \
+    do {                                                                                            \
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(1)))                          \
+            g_tacc[threadIdx.x >> 6][id] += (unsigned long long)(__builtin_readcyclecounter() - v); \
+    } while (0)
+#else
+#define TIC(v) do { } while (0)
+#define TOC(v, id) do { } while (0)
+#endif
+#if defined(RT_DIAG)
 #define DIAG(id)                                                                  \
     do {                                                                          \
         unsigned long long m_ = __ballot(1);                                      \
@@ -268,13 +285,16 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
     const uint32_t tri0 = a.lay.tri_off;  // (indices are absolute)
     if (root_count > 0) {
         // Root is a leaf: every lane tests the same triangles (uniform reads).
+        TIC(t4);
         if (STATS) tri_tests += (int)root_count;
         for (uint32_t j = 0; j < root_count; ++j) {
             const uint32_t t = tri0 + (root_idx + j) * TRI_ISECT_BYTES;
             tri_test<4>(lo, ld, ld4<LDS>(a, t), ld4<LDS>(a, t + 16), ld4<LDS>(a, t + 32), cull, root_idx + j, best);
         }
+        TOC(t4, 4);
         return;
     }
+    TIC(t16);
     const uint32_t wide0 = a.lay.wide_off;
     if (deep) {
         // BVH of height >= 32: the shader's `array<u32,32>` stack can overflow, and what it
@@ -361,6 +381,7 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
         cur = stack[sp * 128];
         cur_count = stack[sp * 128 + 64];
     }
+    TOC(t16, 16);
 }
 
 // A forest item (rt_device.h): meshes with an internal root that share one local space.  The
@@ -379,6 +400,7 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
                             rtm::abs_(lo.x) < INF && rtm::abs_(lo.y) < INF && rtm::abs_(lo.z) < INF;
     const uint32_t e0 = a.lay.forest_off + entry0 * FOREST_ENTRY_BYTES;
     uint32_t todo = 0;  // bit j: member j still to be traversed by this lane
+    TIC(t5);
     for (uint32_t j = 0; j < n_members; ++j) {
         const uint32_t eo = e0 + j * FOREST_ENTRY_BYTES;
         const uint32_t flags = fbits(ld4<LDS>(a, eo).z);
@@ -388,6 +410,7 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
         if (may_hit) todo |= 1u << j;
         else if (STATS) node_tests += 2;  // the shader's two root-level tests (wgsl:322)
     }
+    TOC(t5, 5);
     const uint32_t tri0 = a.lay.tri_off, wide0 = a.lay.wide_off;
     uint32_t cur = 0, cur_count = 0, sp = 0, mesh = 0;
     bool have = false, cull = false;
@@ -396,6 +419,7 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
     b.tri = 0xffffffffu;
     b.u = b.v = b.w = b.det = 0.0f;
     for (;;) {
+        TIC(t8);
         if (!have) {
             if (b.tri != 0xffffffffu) {  // the mesh just left had a hit
                 accept(mesh, b);
@@ -414,7 +438,9 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
                 have = true;
             }
         }
+        TOC(t8, 8);
         if (__ballot(have) == 0ull) break;
+        TIC(t6);
         while (have && cur_count == 0) {  // descend to the next leaf
             DIAG(7);
             const uint32_t wo = wide0 + cur * WIDE_REC_BYTES;
@@ -443,6 +469,8 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
                 cur_count = stack[sp * 128 + 64];
             }
         }
+        TOC(t6, 6);
+        TIC(t7);
         if (have) {  // a leaf
             if (STATS) tri_tests += (int)cur_count;
             for (uint32_t j = 0; j < cur_count; ++j) {
@@ -457,6 +485,7 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
                 cur_count = stack[sp * 128 + 64];
             }
         }
+        TOC(t7, 7);
     }
 }
 
@@ -483,6 +512,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
     // spheres
     float s_dst = 0.0f;
     bool s_inside = false;
+    TIC(t2);
     for (uint32_t i = 0; i < a.n_spheres; ++i) {
         const float4 sp = ld4<LDS>(a, a.lay.sphere_off + i * SPHERE_BYTES);
         f3 oc = ro - f3{sp.x, sp.y, sp.z};
@@ -507,6 +537,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             }
         }
     }
+    TOC(t2, 2);
     // meshes (wgsl:369-393), as items: single meshes and top-level trees over mesh root boxes
     f3 lo{0, 0, 0}, ld{0, 0, 0}, inv{0, 0, 0};
     bool cull_ok = false;
@@ -549,6 +580,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         const uint32_t ia = __builtin_amdgcn_readfirstlane(fbits(item.y));
         if (kind & ITEM_NEW_XFORM) {
             DIAG(3);
+            TIC(t3);
             // meshes with bit-identical world_to_model share the local ray (same inputs, same bits)
             const uint32_t xo = a.lay.mesh_off + __builtin_amdgcn_readfirstlane(fbits(item.z)) * MESH_REC_BYTES;
             const float4 c0 = ld4<LDS>(a, xo), c1 = ld4<LDS>(a, xo + 16), c2 = ld4<LDS>(a, xo + 32),
@@ -560,6 +592,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             if constexpr (TLAS)
                 cull_ok = rtm::abs_(inv.x) < INF && rtm::abs_(inv.y) < INF && rtm::abs_(inv.z) < INF &&
                           rtm::abs_(lo.x) < INF && rtm::abs_(lo.y) < INF && rtm::abs_(lo.z) < INF;
+            TOC(t3, 3);
         }
         if constexpr (!TLAS) if (kind & ITEM_FOREST) {
             traverse_forest<LDS, STATS>(a, ia, __builtin_amdgcn_readfirstlane(fbits(item.w)), lo, ld, inv, stack,
@@ -638,6 +671,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
     h.normal = f3{0, 0, 0};
     h.u = h.v = 0.0f;
     h.backface = false;
+    TIC(t9);
     if (any) {
         DIAG(11);
         if (object >= 0) {
@@ -672,6 +706,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             h.mat_off = a.lay.mat_off + (a.n_meshes + si) * MATERIAL_BYTES;
         }
     }
+    TOC(t9, 9);
     return h;
 }
 
@@ -945,6 +980,7 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
     const bool cache_on = a.pixel_cache != 0;  // wave-uniform
     bool reuse_hit = false;
     DIAG(0);
+    TIC(t1);
     if (s.fresh) {  // wgsl:487-495: next sample of this pixel
         DIAG(1);
         uint32_t st = 0u;
@@ -977,6 +1013,7 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
         s.seg = 0;
         s.fresh = false;
     }
+    TOC(t1, 1);
     bool end_path = true;
     if (s.seg <= nb) {
         // Intersection vote.  Lanes whose segment is a memoised primary ray need no traversal; the
@@ -994,6 +1031,7 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
         }
         Hit hit;
         if (reuse_hit) {
+            TIC(t11);
             with_memo(a, ls, [&](auto pc) {
                 hit.dst = __uint_as_float(pc[3 * 64]);
                 hit.point = f3{__uint_as_float(pc[4 * 64]), __uint_as_float(pc[5 * 64]), __uint_as_float(pc[6 * 64])};
@@ -1005,8 +1043,12 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
                 hit.hit = (w & MEMO_HIT) != 0u;
                 hit.backface = (w & MEMO_BACKFACE) != 0u;
             });
+            TOC(t11, 11);
         } else {
+            TIC(t0);
             hit = intersect_scene<LDS, STATS, TLAS>(a, s.ro, s.rd, stack, node_tests, tri_tests);
+            TOC(t0, 0);
+            TIC(t13);
             if (cache_on && !STATS && s.seg == 0) {
                 with_memo(a, ls, [&](auto pc) {
                     if ((pc[12 * 64] & MEMO_RAY) == 0u) return;
@@ -1020,13 +1062,17 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
                                   MEMO_RAY | MEMO_HIT_VALID;
                 });
             }
+            TOC(t13, 13);
         }
         n_segments += 1;
         if ((s.meta & 0xffffu) != 0xffffu) s.meta += 1;
         if (!hit.hit) {
             DIAG(12);
+            TIC(t10);
             if (a.params.skybox != 0) s.light = s.light + s.T * environment_light(s.rd);
+            TOC(t10, 10);
         } else {
+            TIC(t12);
             const uint32_t mo = hit.mat_off;
             const int flag = ldi<LDS>(a, mo + M_FLAG);
             f3 rd = s.rd;
@@ -1089,6 +1135,7 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
                 end_path = s.seg > nb;
             }
             s.T = T;
+            TOC(t12, 12);
         }
     }
     if (end_path) {  // wgsl:496
@@ -1204,6 +1251,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
 #if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
     const unsigned long long t_wave_start = __builtin_amdgcn_s_memrealtime();
 #endif
+#if defined(RT_DIAGT)
+    if ((threadIdx.x & 63u) < 24u) g_tacc[threadIdx.x >> 6][threadIdx.x & 63u] = 0ull;
+#endif
     uint32_t* ls = block_prologue<LDS>(a);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_tiles = a.tiles_x * a.tiles_y;
@@ -1224,6 +1274,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
 
     for (;;) {
         const unsigned long long idle = __ballot(!active);
+        TIC(t14);
         if (idle != 0ull && !exhausted) {
             if (pool_left == 0) {
                 uint32_t t = 0;
@@ -1266,10 +1317,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                 pool_left -= n;
             }
         }
+        TOC(t14, 14);
         if (__ballot(active) == 0ull) {
             if (exhausted) break;
             continue;
         }
+        TIC(t15);
         if (active) {
             if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, node_tests, tri_tests)) {
                 DIAG(16);
@@ -1278,8 +1331,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                 active = false;
             }
         }
+        TOC(t15, 15);
     }
     flush_counters<STATS>(a, n_segments, node_tests, tri_tests);
+#if defined(RT_DIAGT)
+    if (lane < 24u) atomicAdd(&g_diag[40 + lane], g_tacc[threadIdx.x >> 6][lane]);
+#endif
 #if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
     if (lane == 0) {
         const uint32_t w = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -1439,7 +1496,7 @@ hipError_t diag_wave_times(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(unsigned long long) * 2 * 8192);
 }
 #endif
-#if defined(RT_DIAG)
+#if defined(RT_DIAG) || defined(RT_DIAGT)
 hipError_t diag_read(unsigned long long* out, bool reset) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 64);
     if (e != hipSuccess) return e;

@@ -21,6 +21,23 @@ SECTIONS = {0: "iteration (path_step)", 1: "sample start (ray gen)", 3: "mesh tr
             16: "pixel_finish"}
 
 
+TIME_SO = os.path.join(ROOT, "ray_tracer_2_amd", "librt2_mi355x_diagt.so")
+TIMED = {0: "intersect_scene (all)", 1: "sample start (ray gen / memo ray)", 2: "spheres", 3: "mesh transform",
+         4: "root-leaf meshes", 5: "forest: root-box marks", 6: "forest: node visits", 7: "forest: leaf triangles",
+         8: "forest: accept + next member", 9: "winner finalize", 10: "miss: sky", 11: "memo hit load",
+         12: "shade (hit)", 13: "memo hit store", 14: "refill / tile pull", 15: "path_step (all)",
+         16: "single-mesh BVH walk"}
+
+
+def build_timed():
+    srcs = [os.path.join(build.CSRC, s) for s in build.PRODUCT_SOURCES]
+    if os.path.exists(TIME_SO) and all(os.path.getmtime(TIME_SO) > os.path.getmtime(s) for s in srcs):
+        return
+    subprocess.run([build.hipcc_path(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
+                    "-fno-fast-math", "-fPIC", "-shared", "-DRT_DIAGT=1", "-I", os.path.join(ROOT, "include"),
+                    *srcs, "-lz", "-o", TIME_SO], check=True)
+
+
 def build_diag():
     srcs = [os.path.join(build.CSRC, s) for s in build.PRODUCT_SOURCES]
     if os.path.exists(DIAG_SO) and all(os.path.getmtime(DIAG_SO) > os.path.getmtime(s) for s in srcs):
@@ -31,11 +48,16 @@ def build_diag():
 
 
 def main():
-    build_diag()
+    timed = "--time" in sys.argv
+    if timed:
+        sys.argv.remove("--time")
+        build_timed()
+    else:
+        build_diag()
     if "--build-only" in sys.argv:
         return
     import ray_tracer_2_amd.lib as lib
-    lib.LIB_PATH = DIAG_SO
+    lib.LIB_PATH = TIME_SO if timed else DIAG_SO
     import ray_tracer_2_amd as rt
     variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (960, 540)
@@ -54,6 +76,12 @@ def main():
     L.rt_diag_read(tr._h, buf, 1)
     tr.render(rt.make_params(W, H, 4, 8, skybox=1, frames=0))
     L.rt_diag_read(tr._h, buf, 1)
+    if timed:
+        tot = buf[40 + 15] + buf[40 + 14]
+        print(f"variant {variant}: {W}x{H}, 8 spp, 4 bounces -- wave-cycles per section (s_memtime), share of path_step + refill")
+        for k, name in TIMED.items():
+            print(f"{name:36s} {buf[40 + k]:16d} {buf[40 + k] / tot:7.1%}")
+        return
     it = buf[0]
     print(f"variant {variant}: {W}x{H}, 8 spp, 4 bounces")
     print(f"{'section':28s} {'wave visits':>12s} {'per iter':>9s} {'avg lanes':>9s} {'util':>6s}")
