@@ -10,6 +10,7 @@ method names (src/rendering/ray_tracer.rs:48-435).
 The render path is the HIP library only; nothing here computes pixels.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -30,6 +31,11 @@ class RayTracer:
                 self._h = None
             raise RtError(rc, msg)
         self.max_width, self.max_height = max_width, max_height
+        # tuning knobs for experiments (results never depend on them): RT2_OPTIONS="forest=0,vote_eighths=5"
+        for kv in os.environ.get("RT2_OPTIONS", "").split(","):
+            if kv.strip():
+                k, v = kv.split("=")
+                self.set_option(k.strip(), int(v))
 
     def _check(self, rc):
         if rc < 0:

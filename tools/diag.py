@@ -24,9 +24,9 @@ SECTIONS = {0: "iteration (path_step)", 1: "sample start (ray gen)", 3: "mesh tr
 TIME_SO = os.path.join(ROOT, "ray_tracer_2_amd", "librt2_mi355x_diagt.so")
 TIMED = {0: "intersect_scene (all)", 1: "sample start (ray gen / memo ray)", 2: "spheres", 3: "mesh transform",
          4: "root-leaf meshes", 5: "forest: root-box marks", 6: "forest: node visits", 7: "forest: leaf triangles",
-         8: "forest: accept + next member", 9: "winner finalize", 10: "miss: sky", 11: "memo hit load",
+         8: "forest: deal tasks, fetch rays", 9: "winner finalize", 10: "miss: sky", 11: "memo hit load",
          12: "shade (hit)", 13: "memo hit store", 14: "refill / tile pull", 15: "path_step (all)",
-         16: "single-mesh BVH walk"}
+         16: "single-mesh BVH walk", 17: "forest: world hit + results back"}
 
 
 def build_timed():
