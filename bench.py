@@ -211,9 +211,9 @@ def main():
                        "rays_per_frame": rays / args.steps, "Mpaths/s": W * H * SPP * args.steps / elapsed / 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "rt_render_persistent_kernel<true, false>", "kernel_ms": kernel_ms,
+                         "kernel": "rt_render_persistent_kernel<true, false, false>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "path is FP32-VALU/latency-bound (SURVEY 8d, DESIGN.md): compulsory HBM bytes are ~66 MB/frame"},
+                         "note": "path is FP32-VALU-issue-bound (SURVEY 8d, DESIGN.md): compulsory HBM bytes are ~66 MB/frame"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, arrays)
