@@ -80,6 +80,8 @@ struct rt_handle {
     uint32_t n_meshes = 0, n_spheres = 0, n_textures = 0, n_nodes = 0, n_triangles = 0;
     uint32_t stack_entries = 1, tlas_entries = 1, n_items = 0;
     bool has_tlas = false;
+    bool stack_wide = false;
+    int force_stack_wide = 0;  // option "stack_wide" = 1: two-dword stack entries even when one would do (tests)
     bool has_forest = false;
     int pixel_cache_opt = 1;  // option "pixel_cache"
     int vote_eighths = 6, vote_patience = 1;  // options "vote_eighths", "vote_patience"
@@ -288,7 +290,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         std::vector<uint32_t> wide_base(n_meshes), root_idx(n_meshes), root_count(n_meshes);
         std::vector<char> deep(n_meshes, 0);
         std::vector<uint32_t> wide_index(n_nodes, 0xffffffffu);  // per original node
-        uint32_t max_height = 0;
+        uint32_t max_height = 0, max_leaf_ref = 0;  // (largest triangle count of a leaf that can go on a stack)
         for (uint32_t i = 0; i < n_meshes; ++i) {
             const rt_mesh_uniform& m = meshes[i];
             uint32_t height = 0;
@@ -332,6 +334,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                     if (c.count > 0) {
                         idx = m.triangle_offset + c.first;
                         cnt = c.count;
+                        if (cnt > max_leaf_ref) max_leaf_ref = cnt;
                     } else {
                         idx = wide_base[i] + wide_index[m.node_offset + local];
                         cnt = 0;
@@ -587,13 +590,15 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->n_nodes = n_nodes;
         h->n_triangles = n_triangles;
         h->stack_entries = max_height ? max_height : 1;
+        // one-dword stack entries hold 7 bits of leaf count and 24 bits of triangle index
+        h->stack_wide = max_leaf_ref > 127u || n_triangles > (1u << 24);
         h->tlas_entries = tlas_entries;
         h->has_tlas = has_tlas;
         h->has_forest = !forest_entries.empty();
         h->n_items = (uint32_t)items.size();
         // LDS residency: blob + the four waves' stacks, cost tables and lane state within the
         // per-workgroup budget (the primary-ray memo goes to LDS only if it still fits, see render_impl)
-        uint64_t stacks = ((uint64_t)h->stack_entries * 128u + (uint64_t)h->tlas_entries * 64u) * sizeof(uint32_t) * WAVES_PER_BLOCK +
+        uint64_t stacks = ((uint64_t)h->stack_entries * (h->stack_wide ? 128u : 64u) + (uint64_t)h->tlas_entries * 64u) * sizeof(uint32_t) * WAVES_PER_BLOCK +
                           8u * 3u * 4u * WAVES_PER_BLOCK + (uint64_t)LANE_STATE_DWORDS * 64u * 4u * WAVES_PER_BLOCK;
         h->lds_scene = (uint64_t)lay.bytes + stacks <= LDS_BUDGET_BYTES;
         h->camera = scene->camera;
@@ -659,6 +664,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         h->pixel_cache_opt = value;
     } else if (n == "tlas") {
         h->use_tlas = value ? 1 : 0;
+    } else if (n == "stack_wide") {
+        h->force_stack_wide = value ? 1 : 0;
     } else if (n == "forest") {
         h->use_forest = value ? 1 : 0;
     } else if (n == "tlas_min") {
@@ -722,6 +729,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.n_textures = h->n_textures;
     a.stack_entries = h->stack_entries;
     a.tlas_entries = h->tlas_entries;
+    a.stack_wide = (h->stack_wide || h->force_stack_wide) ? 1u : 0u;
     a.n_items = h->n_items;
     a.strip_rank = rank;
     a.strip_world = world;

@@ -128,7 +128,8 @@ struct RenderArgs {
     const uint32_t* tile_order;  // optional: tiles sorted by last frame's cost, heaviest first
     uint32_t* tile_cost;         // optional: rays per tile of this frame (feeds the next frame's order)
     uint32_t n_meshes, n_spheres, n_textures, n_items;
-    uint32_t stack_entries;  // per-lane BVH stack depth (2 dwords per entry)
+    uint32_t stack_entries;  // per-lane BVH stack depth
+    uint32_t stack_wide;     // 1 => two dwords per entry (a leaf reference does not fit one dword)
     uint32_t tlas_entries;   // per-lane TLAS stack depth (1 dword per entry), >= 1
     uint32_t many_mesh;      // 1 => use the kernels with top-level trees / root-box culling compiled in
     uint32_t pixel_cache;    // per-lane primary-ray memo (PIXEL_MEMO_DWORDS per lane): 0 off, 1 in LDS,

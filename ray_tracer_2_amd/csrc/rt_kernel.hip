@@ -270,6 +270,36 @@ DEV float aabb_dist(f3 lo, f3 inv, float4 qa, float4 qb, float t) {
     return did_hit ? t_near : INF;
 }
 
+// Per-lane BVH stack in LDS (lane-interleaved columns).  An entry is one dword,
+// leaf: 1 << 31 | count << 24 | first triangle, internal node: wide-record index -- or, for
+// scenes with a leaf of more than 127 triangles (RenderArgs::stack_wide), two dwords (idx, count).
+struct LaneStack {
+    uint32_t* col;  // this lane's column
+    bool wide;      // wave-uniform
+};
+DEV void stack_put(const LaneStack& st, uint32_t e, uint32_t idx, uint32_t cnt) {
+    if (st.wide) {
+        st.col[e * 128u] = idx;
+        st.col[e * 128u + 64u] = cnt;
+    } else {
+        st.col[e * 64u] = cnt ? (0x80000000u | (cnt << 24) | idx) : idx;
+    }
+}
+DEV void stack_get(const LaneStack& st, uint32_t e, uint32_t& idx, uint32_t& cnt) {
+    if (st.wide) {
+        idx = st.col[e * 128u];
+        cnt = st.col[e * 128u + 64u];
+    } else {
+        const uint32_t v = st.col[e * 64u];
+        const bool leaf = (v & 0x80000000u) != 0u;
+        idx = leaf ? (v & 0x00ffffffu) : v;
+        cnt = leaf ? ((v >> 24) & 0x7fu) : 0u;
+    }
+}
+DEV uint32_t stack_dwords(const RenderArgs& a) {
+    return (a.stack_entries ? a.stack_entries : 1u) * (a.stack_wide ? 128u : 64u);
+}
+
 // wgsl:292-335 for one mesh.  A traversal entry is (idx, count): count > 0 is
 // a leaf holding triangles [idx, idx + count), count == 0 is the internal node
 // whose wide record has mesh-local index idx.  `stack` points at this lane's
@@ -283,6 +313,7 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
                        f3 ld, f3 inv, uint32_t* stack,
                        MeshBest& best, int& node_tests, int& tri_tests) {
     const uint32_t tri0 = a.lay.tri_off;  // (indices are absolute)
+    const LaneStack st{stack, a.stack_wide != 0u};
     if (root_count > 0) {
         // Root is a leaf: every lane tests the same triangles (uniform reads).
         TIC(t4);
@@ -300,14 +331,14 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
         // BVH of height >= 32: the shader's `array<u32,32>` stack can overflow, and what it
         // then does is defined by naga's Restrict policy (out-of-range indices are clamped to
         // 31 while stack_index keeps counting).  Reproduce wgsl:297-333 literally.
-        auto slot = [](uint32_t i) { return (i < RT_BVH_STACK ? i : RT_BVH_STACK - 1u) * 128u; };
+        auto slot = [](uint32_t i) { return i < RT_BVH_STACK ? i : RT_BVH_STACK - 1u; };
         uint32_t stack_index = 0;
-        stack[slot(0)] = root_idx;
-        stack[slot(0) + 64] = 0u;
+        stack_put(st, slot(0), root_idx, 0u);
         stack_index = 1;
         while (stack_index > 0) {
             stack_index -= 1;
-            const uint32_t idx = stack[slot(stack_index)], cnt = stack[slot(stack_index) + 64];
+            uint32_t idx, cnt;
+            stack_get(st, slot(stack_index), idx, cnt);
             if (cnt > 0) {
                 if (STATS) tri_tests += (int)cnt;
                 for (uint32_t j = 0; j < cnt; ++j) {
@@ -324,13 +355,11 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
                 const bool left_closer = da < db;
                 const float near_d = left_closer ? da : db, far_d = left_closer ? db : da;
                 if (far_d < best.t) {
-                    stack[slot(stack_index)] = fbits(left_closer ? q3.z : q1.z);
-                    stack[slot(stack_index) + 64] = fbits(left_closer ? q3.w : q1.w);
+                    stack_put(st, slot(stack_index), fbits(left_closer ? q3.z : q1.z), fbits(left_closer ? q3.w : q1.w));
                     stack_index += 1;
                 }
                 if (near_d < best.t) {
-                    stack[slot(stack_index)] = fbits(left_closer ? q1.z : q3.z);
-                    stack[slot(stack_index) + 64] = fbits(left_closer ? q1.w : q3.w);
+                    stack_put(st, slot(stack_index), fbits(left_closer ? q1.z : q3.z), fbits(left_closer ? q1.w : q3.w));
                     stack_index += 1;
                 }
             }
@@ -353,8 +382,7 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
             const uint32_t near_i = fbits(left_closer ? q1.z : q3.z), near_c = fbits(left_closer ? q1.w : q3.w);
             const uint32_t far_i = fbits(left_closer ? q3.z : q1.z), far_c = fbits(left_closer ? q3.w : q1.w);
             if (far_d < best.t) {
-                stack[sp * 128] = far_i;
-                stack[sp * 128 + 64] = far_c;
+                stack_put(st, sp, far_i, far_c);
                 ++sp;
             }
             if (near_d < best.t) {
@@ -366,8 +394,7 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
                     break;
                 }
                 --sp;
-                cur = stack[sp * 128];
-                cur_count = stack[sp * 128 + 64];
+                stack_get(st, sp, cur, cur_count);
             }
         }
         if (finished) break;
@@ -378,8 +405,7 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
         }
         if (sp == 0) break;
         --sp;
-        cur = stack[sp * 128];
-        cur_count = stack[sp * 128 + 64];
+        stack_get(st, sp, cur, cur_count);
     }
     TOC(t16, 16);
 }
@@ -412,6 +438,7 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
     }
     TOC(t5, 5);
     const uint32_t tri0 = a.lay.tri_off, wide0 = a.lay.wide_off;
+    const LaneStack st{stack, a.stack_wide != 0u};
     uint32_t cur = 0, cur_count = 0, sp = 0, mesh = 0;
     bool have = false, cull = false;
     MeshBest b;
@@ -454,8 +481,7 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
             const uint32_t near_i = fbits(left_closer ? q1.z : q3.z), near_c = fbits(left_closer ? q1.w : q3.w);
             const uint32_t far_i = fbits(left_closer ? q3.z : q1.z), far_c = fbits(left_closer ? q3.w : q1.w);
             if (far_d < b.t) {
-                stack[sp * 128] = far_i;
-                stack[sp * 128 + 64] = far_c;
+                stack_put(st, sp, far_i, far_c);
                 ++sp;
             }
             if (near_d < b.t) {
@@ -465,8 +491,7 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
                 have = false;
             } else {
                 --sp;
-                cur = stack[sp * 128];
-                cur_count = stack[sp * 128 + 64];
+                stack_get(st, sp, cur, cur_count);
             }
         }
         TOC(t6, 6);
@@ -481,8 +506,7 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
                 have = false;
             } else {
                 --sp;
-                cur = stack[sp * 128];
-                cur_count = stack[sp * 128 + 64];
+                stack_get(st, sp, cur, cur_count);
             }
         }
         TOC(t7, 7);
@@ -505,7 +529,7 @@ template <bool LDS, bool STATS, bool TLAS>
 DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int& node_tests,
                         int& tri_tests) {
     // this lane's TLAS stack column sits behind the wave's BVH stack columns
-    uint32_t* tstack = stack + (a.stack_entries ? a.stack_entries : 1u) * 128u;
+    uint32_t* tstack = stack + stack_dwords(a);
     float closest = INF;
     int object = 0;  // >= 0 mesh index, < 0 sphere -(index) - 1
     bool any = false;
@@ -798,7 +822,7 @@ DEV void store_texel(const A& a, uint32_t x, uint32_t out_row, f4 cur) {
 DEV uint32_t lane_state_dwords(const RenderArgs& a) { return a.lds_scene ? LANE_STATE_DWORDS : 0u; }
 DEV uint32_t wave_region_dwords(const RenderArgs& a) {
     return (a.pixel_cache == 1u ? PIXEL_MEMO_DWORDS * 64u : 0u) + lane_state_dwords(a) * 64u +
-           (a.stack_entries ? a.stack_entries : 1u) * 128u + a.tlas_entries * 64u;
+           stack_dwords(a) + a.tlas_entries * 64u;
 }
 
 // Stage the scene blob into LDS (coalesced 16-byte loads, whole workgroup) and
@@ -1510,7 +1534,7 @@ hipError_t diag_read(unsigned long long* out, bool reset) {
 
 // Launchers (called from rt_api.hip)
 size_t render_lds_bytes(const RenderArgs& a) {
-    size_t stacks = ((size_t)(a.stack_entries ? a.stack_entries : 1u) * 128u + (size_t)a.tlas_entries * 64u) *
+    size_t stacks = ((size_t)(a.stack_entries ? a.stack_entries : 1u) * (a.stack_wide ? 128u : 64u) + (size_t)a.tlas_entries * 64u) *
                     sizeof(uint32_t) * WAVES_PER_BLOCK;
     size_t cost_tables = 8u * 3u * sizeof(uint32_t) * WAVES_PER_BLOCK;
     size_t lane_state = a.lds_scene ? (size_t)LANE_STATE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;

@@ -240,6 +240,35 @@ def dragon_arrays(rt):
     return rt.SceneArrays.from_scene(sc)
 
 
+@pytest.mark.parametrize("knobs", [{"forest": 0}, {"stack_wide": 1}, {"pixel_cache": 0}, {"pixel_cache": 2},
+                                   {"forest": 0, "stack_wide": 1, "pixel_cache": 2}],
+                         ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+def test_tuning_knobs_do_not_change_the_bits(rt, oracle, tracer, cornell, dragon_arrays, knobs):
+    """rt_set_option's contract: results never depend on the knobs (forest items, stack entry
+    width, memo placement) -- on the LDS-resident Cornell scene and the global-memory dragon scene."""
+    defaults = {"forest": 1, "stack_wide": 0, "pixel_cache": 1}
+    try:
+        for name, value in knobs.items():
+            tracer.set_option(name, value)
+        for arrays, (w, h, spp) in ((cornell, (192, 108, 8)), (dragon_arrays, (128, 72, 4))):
+            tracer.load_scene(arrays)   # "forest" takes effect at upload
+            p = rt.make_params(w, h, 4, spp, skybox=1, frames=0)
+            tracer.set_counters(True)
+            tracer.reset_timing()
+            tracer.render(p)
+            gpu = tracer.read_image(w, h)
+            s = tracer.stats()
+            tracer.set_counters(False)
+            ref, st = oracle.render(p, arrays)
+            assert same(gpu, ref), knobs
+            assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests)
+            tracer.render(p)  # and the product kernels (no counters)
+            assert same(tracer.read_image(w, h), ref), knobs
+    finally:
+        for name, value in defaults.items():
+            tracer.set_option(name, value)
+
+
 def test_config3_dragon_standin(rt, oracle, tracer, dragon_arrays):
     """BVH far larger than LDS (global-memory scene path), 16 spp, 4 bounces, bit-exact; plus the
     traversal counters (debug views 5-7 and rt_stats) against the oracle's."""
