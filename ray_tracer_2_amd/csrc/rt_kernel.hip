@@ -522,20 +522,43 @@ struct Hit {
     uint32_t mat_off; // byte offset of the winner's material in the blob
 };
 
-// wgsl:353-396 (+ ray_sphere :223-256).  Per-object outputs that only the
-// overall winner needs (normals, uv) are computed once after the loops from
-// the same inputs, which yields the same bits.
-template <bool LDS, bool STATS, bool TLAS>
-DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int& node_tests,
-                        int& tri_tests) {
-    // this lane's TLAS stack column sits behind the wave's BVH stack columns
-    uint32_t* tstack = stack + stack_dwords(a);
+// world-space hit point and distance of a mesh-local hit at parameter t (wgsl:380-381); m2w =
+// byte offset of the four model_to_world columns
+template <bool LDS>
+DEV void world_hit(const RenderArgs& a, uint32_t m2w, f3 lo, f3 ld, f3 ro, float t, f3& whp, float& wdst) {
+    const float4 c0 = ld4<LDS>(a, m2w), c1 = ld4<LDS>(a, m2w + 16), c2 = ld4<LDS>(a, m2w + 32), c3 = ld4<LDS>(a, m2w + 48);
+    f3 lhp = lo + ld * t;
+    whp = mat_cols_xyz(c0, c1, c2, c3, lhp, 1.0f);
+    f3 dv = ro - whp;
+    wdst = rtm::sqrt_(dot3(dv, dv));
+}
+
+// Closest-hit record of one scene intersection (wgsl:353-396).
+struct Isect {
     float closest = INF;
     int object = 0;  // >= 0 mesh index, < 0 sphere -(index) - 1
     bool any = false;
-    // spheres
-    float s_dst = 0.0f;
+    float s_dst = 0.0f;     // sphere winner: distance, inside flag
     bool s_inside = false;
+    MeshBest win{};         // mesh winner: its triangle data and world hit point
+    f3 win_point{0, 0, 0};
+};
+
+// closest-hit update of wgsl:383-391; equal distances go to the lower mesh index, which is
+// what the shader's in-order loop with its strict `<` yields
+DEV void isect_offer(Isect& I, uint32_t i, const MeshBest& b, f3 whp, float wdst) {
+    if (wdst < I.closest || (wdst == I.closest && I.any && I.object >= 0 && (int)i < I.object)) {
+        I.closest = wdst;
+        I.any = true;
+        I.object = (int)i;
+        I.win = b;
+        I.win_point = whp;
+    }
+}
+
+// ray_sphere over all spheres (wgsl:223-256, 359-367)
+template <bool LDS>
+DEV void isect_spheres(const RenderArgs& a, f3 ro, f3 rd, Isect& I) {
     TIC(t2);
     for (uint32_t i = 0; i < a.n_spheres; ++i) {
         const float4 sp = ld4<LDS>(a, a.lay.sphere_off + i * SPHERE_BYTES);
@@ -551,40 +574,87 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             if (dst_far >= 0.001f) {
                 bool inside = dst_near == 0.0f;
                 float dst = inside ? dst_far : dst_near;
-                if (dst < closest) {
-                    closest = dst;
-                    any = true;
-                    object = -(int)i - 1;
-                    s_dst = dst;
-                    s_inside = inside;
+                if (dst < I.closest) {
+                    I.closest = dst;
+                    I.any = true;
+                    I.object = -(int)i - 1;
+                    I.s_dst = dst;
+                    I.s_inside = inside;
                 }
             }
         }
     }
     TOC(t2, 2);
+}
+
+// Per-object outputs that only the overall winner needs (normals, uv) are computed once after
+// the loops from the same inputs, which yields the same bits.
+template <bool LDS>
+DEV Hit isect_finish(const RenderArgs& a, const Isect& I, f3 ro, f3 rd) {
+    Hit h;
+    h.hit = I.any;
+    h.dst = I.closest;
+    h.mat_off = 0;
+    h.point = f3{0, 0, 0};
+    h.normal = f3{0, 0, 0};
+    h.u = h.v = 0.0f;
+    h.backface = false;
+    TIC(t9);
+    if (I.any) {
+        DIAG(11);
+        if (I.object >= 0) {
+            const uint32_t mo = a.lay.mesh_off + (uint32_t)I.object * MESH_REC_BYTES;
+            const uint32_t so = a.lay.shade_off + I.win.tri * TRI_SHADE_BYTES;
+            const float4 s0 = ld4<LDS>(a, so), s1 = ld4<LDS>(a, so + 16), s2 = ld4<LDS>(a, so + 32),
+                         s3 = ld4<LDS>(a, so + 48);
+            f3 n1{s0.x, s0.y, s0.z}, n2{s1.x, s1.y, s1.z}, n3{s2.x, s2.y, s2.z};
+            f3 ln = normalize3((n1 * I.win.w + n2 * I.win.u) + n3 * I.win.v) * sign_(I.win.det);
+            const float4 c0 = ld4<LDS>(a, mo + 64), c1 = ld4<LDS>(a, mo + 80), c2 = ld4<LDS>(a, mo + 96),
+                         c3 = ld4<LDS>(a, mo + 112);
+            h.normal = normalize3(mat_cols_xyz(c0, c1, c2, c3, ln, 0.0f));
+            h.backface = I.win.det < 0.0f;
+            h.point = I.win_point;
+            // uv = (uv1 * w + uv2 * u) + uv3 * v, uv1 = (u10,u11), uv2 = (u20,u21), uv3 = (u30,u31)
+            h.u = (s0.w * I.win.w + s2.w * I.win.u) + s3.y * I.win.v;
+            h.v = (s1.w * I.win.w + s3.x * I.win.u) + s3.z * I.win.v;
+            h.mat_off = a.lay.mat_off + (uint32_t)I.object * MATERIAL_BYTES;
+        } else {
+            const uint32_t si = (uint32_t)(-I.object - 1);
+            const float4 sp = ld4<LDS>(a, a.lay.sphere_off + si * SPHERE_BYTES);
+            f3 c{sp.x, sp.y, sp.z};
+            h.point = ro + rd * I.s_dst;
+            f3 n = normalize3(h.point - c);
+            h.normal = I.s_inside ? -n : n;
+            h.backface = I.s_inside;
+            const float pi = 3.1415926f;
+            float theta = rtm::acos_(-h.normal.y);
+            float phi = rtm::atan2_(-h.normal.z, -h.normal.x) + pi;
+            h.u = phi / (2.0f * pi);
+            h.v = theta / pi;
+            h.mat_off = a.lay.mat_off + (a.n_meshes + si) * MATERIAL_BYTES;
+        }
+    }
+    TOC(t9, 9);
+    return h;
+}
+
+// wgsl:353-396 (+ ray_sphere :223-256).
+template <bool LDS, bool STATS, bool TLAS>
+DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int& node_tests,
+                        int& tri_tests) {
+    // this lane's TLAS stack column sits behind the wave's BVH stack columns
+    uint32_t* tstack = stack + stack_dwords(a);
+    Isect I;
+    isect_spheres<LDS>(a, ro, rd, I);
     // meshes (wgsl:369-393), as items: single meshes and top-level trees over mesh root boxes
     f3 lo{0, 0, 0}, ld{0, 0, 0}, inv{0, 0, 0};
     bool cull_ok = false;
-    MeshBest win{};  // winner's triangle data
-    f3 win_point{0, 0, 0};
-    // closest-hit update of wgsl:383-391; equal distances go to the lower mesh index, which is
-    // what the shader's in-order loop with its strict `<` yields
     auto accept_mesh_hit = [&](uint32_t i, const MeshBest& b) {
         DIAG(10);
-        const uint32_t mo = a.lay.mesh_off + i * MESH_REC_BYTES;
-        const float4 c0 = ld4<LDS>(a, mo + 64), c1 = ld4<LDS>(a, mo + 80), c2 = ld4<LDS>(a, mo + 96),
-                     c3 = ld4<LDS>(a, mo + 112);
-        f3 lhp = lo + ld * b.t;
-        f3 whp = mat_cols_xyz(c0, c1, c2, c3, lhp, 1.0f);
-        f3 dv = ro - whp;
-        float wdst = rtm::sqrt_(dot3(dv, dv));
-        if (wdst < closest || (wdst == closest && any && object >= 0 && (int)i < object)) {
-            closest = wdst;
-            any = true;
-            object = (int)i;
-            win = b;
-            win_point = whp;
-        }
+        f3 whp;
+        float wdst;
+        world_hit<LDS>(a, a.lay.mesh_off + i * MESH_REC_BYTES + 64u, lo, ld, ro, b.t, whp, wdst);
+        isect_offer(I, i, b, whp, wdst);
     };
     auto visit_mesh = [&](uint32_t i, float4 hdr) {
         const uint32_t flags = fbits(hdr.x);
@@ -687,51 +757,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             }
         }
     }
-    Hit h;
-    h.hit = any;
-    h.dst = closest;
-    h.mat_off = 0;
-    h.point = f3{0, 0, 0};
-    h.normal = f3{0, 0, 0};
-    h.u = h.v = 0.0f;
-    h.backface = false;
-    TIC(t9);
-    if (any) {
-        DIAG(11);
-        if (object >= 0) {
-            const uint32_t mo = a.lay.mesh_off + (uint32_t)object * MESH_REC_BYTES;
-            const uint32_t so = a.lay.shade_off + win.tri * TRI_SHADE_BYTES;
-            const float4 s0 = ld4<LDS>(a, so), s1 = ld4<LDS>(a, so + 16), s2 = ld4<LDS>(a, so + 32),
-                         s3 = ld4<LDS>(a, so + 48);
-            f3 n1{s0.x, s0.y, s0.z}, n2{s1.x, s1.y, s1.z}, n3{s2.x, s2.y, s2.z};
-            f3 ln = normalize3((n1 * win.w + n2 * win.u) + n3 * win.v) * sign_(win.det);
-            const float4 c0 = ld4<LDS>(a, mo + 64), c1 = ld4<LDS>(a, mo + 80), c2 = ld4<LDS>(a, mo + 96),
-                         c3 = ld4<LDS>(a, mo + 112);
-            h.normal = normalize3(mat_cols_xyz(c0, c1, c2, c3, ln, 0.0f));
-            h.backface = win.det < 0.0f;
-            h.point = win_point;
-            // uv = (uv1 * w + uv2 * u) + uv3 * v, uv1 = (u10,u11), uv2 = (u20,u21), uv3 = (u30,u31)
-            h.u = (s0.w * win.w + s2.w * win.u) + s3.y * win.v;
-            h.v = (s1.w * win.w + s3.x * win.u) + s3.z * win.v;
-            h.mat_off = a.lay.mat_off + (uint32_t)object * MATERIAL_BYTES;
-        } else {
-            const uint32_t si = (uint32_t)(-object - 1);
-            const float4 sp = ld4<LDS>(a, a.lay.sphere_off + si * SPHERE_BYTES);
-            f3 c{sp.x, sp.y, sp.z};
-            h.point = ro + rd * s_dst;
-            f3 n = normalize3(h.point - c);
-            h.normal = s_inside ? -n : n;
-            h.backface = s_inside;
-            const float pi = 3.1415926f;
-            float theta = rtm::acos_(-h.normal.y);
-            float phi = rtm::atan2_(-h.normal.z, -h.normal.x) + pi;
-            h.u = phi / (2.0f * pi);
-            h.v = theta / pi;
-            h.mat_off = a.lay.mat_off + (a.n_meshes + si) * MATERIAL_BYTES;
-        }
-    }
-    TOC(t9, 9);
-    return h;
+    return isect_finish<LDS>(a, I, ro, rd);
 }
 
 // field byte offsets inside rt_material
@@ -986,13 +1012,19 @@ DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts&
     });
 }
 
-// One iteration of the per-lane state machine: (start the next sample) + one
-// path segment + its shading.  Returns true when the pixel's last sample ended.
-template <bool LDS, bool STATS, bool TLAS>
-DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
-                   int& node_tests, int& tri_tests) {
+// One iteration of the per-lane state machine = path_begin (start the next sample, decide what
+// this lane does now) + the segment's hit (memo or scene intersection) + path_end (shading,
+// russian roulette, end of path).  path_end returns true when the pixel's last sample ended.
+enum : uint32_t {
+    STEP_END = 0,       // bounce budget used up: the path ends without another segment
+    STEP_WAIT = 1,      // wants a traversal but the wave voted against one now
+    STEP_REUSE = 2,     // memoised primary ray: take its hit from the memo
+    STEP_TRAVERSE = 3,  // intersect the scene
+};
+
+template <bool STATS>
+DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve) {
     const int32_t nb = a.params.number_of_bounces;
-    uint32_t* stack = stack_of<LDS>(ls);
     // Primary-ray memo.  With defocus_strength = diverge_strength = +0 (the default camera) the
     // camera jitter is +-0, and unless a component of the camera origin or of the pixel's focus
     // point is -0 the sums `origin + right*j.x + up*j.y` do not depend on those signs: every
@@ -1038,56 +1070,67 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
         s.fresh = false;
     }
     TOC(t1, 1);
+    if (s.seg > nb) return STEP_END;
+    // Intersection vote.  Lanes whose segment is a memoised primary ray need no traversal; the
+    // others do.  The traversal is the expensive part of an iteration and the wave pays for
+    // it whenever a single lane needs it, so it only runs when enough of the lanes here want
+    // it (or somebody has already waited); the waiting lanes simply take their turn in the
+    // next iteration, by which time the memoised-primary lanes have moved on to secondary
+    // segments and want it too.  Pure scheduling: no lane's sequence of operations changes.
+    if (cache_on) {
+        const uint32_t n_here = (uint32_t)__popcll(__ballot(true));
+        const uint32_t n_want = (uint32_t)__popcll(__ballot(!reuse_hit));
+        const bool run = n_want * 8u >= n_here * a.vote_eighths || starve >= a.vote_patience;
+        starve = (n_want != 0u && !run) ? starve + 1u : 0u;
+        if (!reuse_hit && !run) return STEP_WAIT;  // nothing about this lane has changed
+    }
+    return reuse_hit ? STEP_REUSE : STEP_TRAVERSE;
+}
+
+DEV void memo_hit_load(const RenderArgs& a, uint32_t* ls, Hit& hit) {
+    TIC(t11);
+    with_memo(a, ls, [&](auto pc) {
+        hit.dst = __uint_as_float(pc[3 * 64]);
+        hit.point = f3{__uint_as_float(pc[4 * 64]), __uint_as_float(pc[5 * 64]), __uint_as_float(pc[6 * 64])};
+        hit.normal = f3{__uint_as_float(pc[7 * 64]), __uint_as_float(pc[8 * 64]), __uint_as_float(pc[9 * 64])};
+        hit.u = __uint_as_float(pc[10 * 64]);
+        hit.v = __uint_as_float(pc[11 * 64]);
+        const uint32_t w = pc[12 * 64];
+        hit.mat_off = w & ~15u;  // material records are 16-byte aligned
+        hit.hit = (w & MEMO_HIT) != 0u;
+        hit.backface = (w & MEMO_BACKFACE) != 0u;
+    });
+    TOC(t11, 11);
+}
+
+// the memoised ray's hit goes into the memo the first time it is computed
+template <bool STATS>
+DEV void memo_hit_store(const RenderArgs& a, const PixelState& s, uint32_t* ls, const Hit& hit) {
+    TIC(t13);
+    const bool cache_on = a.pixel_cache != 0;
+    if (cache_on && !STATS && s.seg == 0) {
+        with_memo(a, ls, [&](auto pc) {
+            if ((pc[12 * 64] & MEMO_RAY) == 0u) return;
+            // the memoised ray's hit
+            pc[3 * 64] = __float_as_uint(hit.dst);
+            pc[4 * 64] = __float_as_uint(hit.point.x); pc[5 * 64] = __float_as_uint(hit.point.y); pc[6 * 64] = __float_as_uint(hit.point.z);
+            pc[7 * 64] = __float_as_uint(hit.normal.x); pc[8 * 64] = __float_as_uint(hit.normal.y); pc[9 * 64] = __float_as_uint(hit.normal.z);
+            pc[10 * 64] = __float_as_uint(hit.u);
+            pc[11 * 64] = __float_as_uint(hit.v);
+            pc[12 * 64] = (hit.hit ? (hit.mat_off & ~15u) | MEMO_HIT : 0u) | (hit.backface ? MEMO_BACKFACE : 0u) |
+                          MEMO_RAY | MEMO_HIT_VALID;
+        });
+    }
+    TOC(t13, 13);
+}
+
+// LDS: material reads from LDS; TOTAL_LDS: the pixel sum lives in the lane's LDS state
+template <bool LDS, bool TOTAL_LDS>
+DEV bool path_end(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t mode, const Hit& hit,
+                  uint32_t& n_segments) {
+    const int32_t nb = a.params.number_of_bounces;
     bool end_path = true;
-    if (s.seg <= nb) {
-        // Intersection vote.  Lanes whose segment is a memoised primary ray need no traversal; the
-        // others do.  The traversal is the expensive part of an iteration and the wave pays for
-        // it whenever a single lane needs it, so it only runs when enough of the lanes here want
-        // it (or somebody has already waited); the waiting lanes simply take their turn in the
-        // next iteration, by which time the memoised-primary lanes have moved on to secondary
-        // segments and want it too.  Pure scheduling: no lane's sequence of operations changes.
-        if (cache_on) {
-            const uint32_t n_here = (uint32_t)__popcll(__ballot(true));
-            const uint32_t n_want = (uint32_t)__popcll(__ballot(!reuse_hit));
-            const bool run = n_want * 8u >= n_here * a.vote_eighths || starve >= a.vote_patience;
-            starve = (n_want != 0u && !run) ? starve + 1u : 0u;
-            if (!reuse_hit && !run) return false;  // wait; nothing about this lane has changed
-        }
-        Hit hit;
-        if (reuse_hit) {
-            TIC(t11);
-            with_memo(a, ls, [&](auto pc) {
-                hit.dst = __uint_as_float(pc[3 * 64]);
-                hit.point = f3{__uint_as_float(pc[4 * 64]), __uint_as_float(pc[5 * 64]), __uint_as_float(pc[6 * 64])};
-                hit.normal = f3{__uint_as_float(pc[7 * 64]), __uint_as_float(pc[8 * 64]), __uint_as_float(pc[9 * 64])};
-                hit.u = __uint_as_float(pc[10 * 64]);
-                hit.v = __uint_as_float(pc[11 * 64]);
-                const uint32_t w = pc[12 * 64];
-                hit.mat_off = w & ~15u;  // material records are 16-byte aligned
-                hit.hit = (w & MEMO_HIT) != 0u;
-                hit.backface = (w & MEMO_BACKFACE) != 0u;
-            });
-            TOC(t11, 11);
-        } else {
-            TIC(t0);
-            hit = intersect_scene<LDS, STATS, TLAS>(a, s.ro, s.rd, stack, node_tests, tri_tests);
-            TOC(t0, 0);
-            TIC(t13);
-            if (cache_on && !STATS && s.seg == 0) {
-                with_memo(a, ls, [&](auto pc) {
-                    if ((pc[12 * 64] & MEMO_RAY) == 0u) return;
-                    // the memoised ray's hit
-                    pc[3 * 64] = __float_as_uint(hit.dst);
-                    pc[4 * 64] = __float_as_uint(hit.point.x); pc[5 * 64] = __float_as_uint(hit.point.y); pc[6 * 64] = __float_as_uint(hit.point.z);
-                    pc[7 * 64] = __float_as_uint(hit.normal.x); pc[8 * 64] = __float_as_uint(hit.normal.y); pc[9 * 64] = __float_as_uint(hit.normal.z);
-                    pc[10 * 64] = __float_as_uint(hit.u);
-                    pc[11 * 64] = __float_as_uint(hit.v);
-                    pc[12 * 64] = (hit.hit ? (hit.mat_off & ~15u) | MEMO_HIT : 0u) | (hit.backface ? MEMO_BACKFACE : 0u) |
-                                  MEMO_RAY | MEMO_HIT_VALID;
-                });
-            }
-            TOC(t13, 13);
-        }
+    if (mode != STEP_END) {
         n_segments += 1;
         if ((s.meta & 0xffffu) != 0xffffu) s.meta += 1;
         if (!hit.hit) {
@@ -1163,7 +1206,7 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
         }
     }
     if (end_path) {  // wgsl:496
-        if constexpr (LDS) {
+        if constexpr (TOTAL_LDS) {
             ls[0] = __float_as_uint(__uint_as_float(ls[0]) + s.light.x);  // total += incoming_light
             ls[64] = __float_as_uint(__uint_as_float(ls[64]) + s.light.y);
             ls[128] = __float_as_uint(__uint_as_float(ls[128]) + s.light.z);
@@ -1176,6 +1219,24 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
         return s.j >= a.params.rays_per_pixel;
     }
     return false;
+}
+
+template <bool LDS, bool STATS, bool TLAS>
+DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
+                   int& node_tests, int& tri_tests) {
+    const uint32_t mode = path_begin<STATS>(a, s, ls, starve);
+    if (mode == STEP_WAIT) return false;
+    Hit hit;
+    hit.hit = false;
+    if (mode == STEP_REUSE) {
+        memo_hit_load(a, ls, hit);
+    } else if (mode == STEP_TRAVERSE) {
+        TIC(t0);
+        hit = intersect_scene<LDS, STATS, TLAS>(a, s.ro, s.rd, stack_of<LDS>(ls), node_tests, tri_tests);
+        TOC(t0, 0);
+        memo_hit_store<STATS>(a, s, ls, hit);
+    }
+    return path_end<LDS, LDS>(a, s, ls, mode, hit, n_segments);
 }
 
 // wgsl:498 + 154-161

@@ -21,7 +21,8 @@ def main():
         sc = scenes.cornell_dragon(scenes.load_raw_meshes(os.path.join(g, "cornell_raw.npz")),
                                    scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")), subdivide=n)
     arrays = rt.SceneArrays.from_scene(sc)
-    W, H = 1920, 1080
+    W, H = (int(os.environ.get("BS_W", 1920)), int(os.environ.get("BS_H", 1080)))   # BS_W=3840 BS_H=2160 BS_BOUNCES=8: config 5 at full size
+    NB = int(os.environ.get("BS_BOUNCES", 4))
     tr = rt.RayTracer(0, W, H)
     for kv in os.environ.get("BS_OPTS", "").split(","):   # e.g. BS_OPTS=forest=0,tlas=0 (upload-time options too)
         if kv:
@@ -29,13 +30,13 @@ def main():
             tr.set_option(k, int(v))
     tr.load_scene(arrays)
     print(f"triangles {arrays.triangles.shape[0]}, nodes {arrays.nodes.shape[0]}, meshes {arrays.meshes.shape[0]}")
-    for variant in (0, 1):
+    for variant in ((0,) if os.environ.get("BS_W") else (0, 1)):
         tr.set_option("kernel_variant", variant)
         ts, rays = [], 0
         for r in range(4):
             tr.reset_timing()
             for f in range(3):
-                tr.render(rt.make_params(W, H, 4, spp, skybox=1, frames=1 + f))
+                tr.render(rt.make_params(W, H, NB, spp, skybox=1, frames=1 + f))
             st = tr.stats()
             if r:
                 ts.append(st.kernel_ms / st.launches)
