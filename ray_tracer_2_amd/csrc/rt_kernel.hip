@@ -1046,10 +1046,9 @@ DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32
                 s.rd = f3{__uint_as_float(pc[0]), __uint_as_float(pc[64]), __uint_as_float(pc[128])};
             });
         if (st & MEMO_RAY) {
-            (void)next_random_number(s.rng);  // the two disks' angle and radius draws
-            (void)next_random_number(s.rng);
-            (void)next_random_number(s.rng);
-            (void)next_random_number(s.rng);
+            // the two disks' angle and radius draws: four steps of the generator's LCG
+            // s -> s * 747796405 + 2891336453 (mod 2^32) in one, (A^4, C (A^3 + A^2 + A + 1)); exact
+            s.rng = s.rng * 2200120369u + 878960812u;
             s.ro = f3{a.memo_ro[0], a.memo_ro[1], a.memo_ro[2]};
             reuse_hit = !STATS && (st & MEMO_HIT_VALID) != 0u;
         } else {
