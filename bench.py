@@ -195,11 +195,20 @@ def main():
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
         # (profiles/run_profile.sh; FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024): PMC counters
         # cannot be read from inside the process, so the figure is the profiled one or null.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         if world == 1 and (W, H) == (WIDTH, HEIGHT) and os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
+            if "valu_instructions_per_launch" in tj:
+                # the bound that matters: VALU issue.  A SIMD issues one wave64 VALU
+                # instruction per 4 cycles; instruction count and clock come from the same rocprofv3 passes.
+                simds = torch.cuda.get_device_properties(device).multi_processor_count * 4
+                clock = tj.get("shader_clock_ghz", 2.4)
+                rate = tj["valu_instructions_per_launch"] / (kernel_ms * 1e-3) / 1e9
+                valu = {"bound": "valu_issue", "achieved": rate, "peak": simds * clock / 4.0, "unit": "G wave-instructions/s",
+                        "frac": rate / (simds * clock / 4.0), "lane_utilisation": tj.get("valu_lane_utilisation"),
+                        "source": tj["source"].replace("FETCH_SIZE / WRITE_SIZE", "SQ_INSTS_VALU / GRBM_GUI_ACTIVE")}
         out = {
             "metric": "Mrays/s", "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -215,6 +224,13 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "path is FP32-VALU-issue-bound (SURVEY 8d, DESIGN.md): compulsory HBM bytes are ~66 MB/frame"},
         }
+        if valu is not None:
+            out["roofline_valu"] = valu
+        # which kernel the library's automatic choice runs for this shape (rt_api.hip render_impl)
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        tiles = ((W + 7) // 8) * (texels // W // 8 if world > 1 else (H + 7) // 8)
+        if args.variant == 1 or (args.variant is None and tiles * 4 <= cus * 16 * 5):
+            out["roofline"]["kernel"] = "rt_render_tiles_kernel<true, false, false>"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, arrays)
         print(json.dumps(out), flush=True)

@@ -258,7 +258,7 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  * "vote_eighths" (0..8, default 6) and
  * "vote_patience" (default 1) = the intersection vote of the render kernels; "tile_feedback" 0 = do not
  * reorder tiles by the previous frame's per-tile ray counts; "forest" 0 = no forest items (next
- * upload); "stack_wide" 1 = two-dword BVH stack entries even when one dword would do. */
+ * upload); "stack_wide" -1 auto / 0 one-dword BVH stack entries whenever legal / 1 two-dword entries. */
 int rt_set_option(rt_handle* h, const char* name, int value);
 /* Enable/disable the optional per-ray counters (node/triangle tests). */
 int rt_set_counters(rt_handle* h, int enabled);

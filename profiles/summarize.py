@@ -51,8 +51,15 @@ def main():
         fetch = agg["FETCH_SIZE"] * 1024 * 2  # KiB -> B, gfx950 x2 correction for 16 B/lane reads
         write = agg["WRITE_SIZE"] * 1024
         import json
-        json.dump({"bytes_per_launch": fetch + write, "source": f"profiles/{tag}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"},
-                  open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "latest_traffic.json"), "w"))
+        rec = {"bytes_per_launch": fetch + write, "source": f"profiles/{tag}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
+        if "SQ_INSTS_VALU" in agg:
+            rec["valu_instructions_per_launch"] = agg["SQ_INSTS_VALU"]
+        if "SQ_THREAD_CYCLES_VALU" in agg and "SQ_ACTIVE_INST_VALU" in agg:
+            rec["valu_lane_utilisation"] = agg["SQ_THREAD_CYCLES_VALU"] / (64 * agg["SQ_ACTIVE_INST_VALU"])
+        if "GRBM_GUI_ACTIVE" in agg and tr:
+            dur_ = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in tr) / len(tr) * 1e-9
+            rec["shader_clock_ghz"] = agg["GRBM_GUI_ACTIVE"] / 8 / dur_ / 1e9
+        json.dump(rec, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "latest_traffic.json"), "w"))
         lines.append(f"HBM traffic per launch: read {fetch / 1e6:.1f} MB (FETCH_SIZE x 1024 x 2) + write {write / 1e6:.1f} MB "
                      f"(WRITE_SIZE x 1024) = {(fetch + write) / 1e6:.1f} MB; algorithmic 66.4 MB")
     if "SQ_INSTS_VALU" in agg and "SQ_WAVES" in agg:

@@ -80,8 +80,8 @@ struct rt_handle {
     uint32_t n_meshes = 0, n_spheres = 0, n_textures = 0, n_nodes = 0, n_triangles = 0;
     uint32_t stack_entries = 1, tlas_entries = 1, n_items = 0;
     bool has_tlas = false;
-    bool stack_wide = false;
-    int force_stack_wide = 0;  // option "stack_wide" = 1: two-dword stack entries even when one would do (tests)
+    bool stack_wide = false, stack_must_wide = false;
+    int force_stack_wide = -1;  // option "stack_wide": -1 auto, 0 one-dword entries when legal, 1 two-dword entries
     bool has_forest = false;
     int pixel_cache_opt = 1;  // option "pixel_cache"
     int vote_eighths = 6, vote_patience = 1;  // options "vote_eighths", "vote_patience"
@@ -590,8 +590,17 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->n_nodes = n_nodes;
         h->n_triangles = n_triangles;
         h->stack_entries = max_height ? max_height : 1;
-        // one-dword stack entries hold 7 bits of leaf count and 24 bits of triangle index
-        h->stack_wide = max_leaf_ref > 127u || n_triangles > (1u << 24);
+        // One-dword stack entries hold 7 bits of leaf count and 24 bits of triangle index; they cost
+        // a few instructions per push/pop, so they are used when they buy occupancy: when two-dword
+        // entries would not leave room for the scene blob and the primary-ray memo in LDS.
+        {
+            const uint64_t fixed = 8u * 3u * 4u * WAVES_PER_BLOCK + (uint64_t)(LANE_STATE_DWORDS + PIXEL_MEMO_DWORDS) * 64u * 4u * WAVES_PER_BLOCK +
+                                   (uint64_t)tlas_entries * 64u * 4u * WAVES_PER_BLOCK;
+            const uint64_t wide_stacks = (uint64_t)h->stack_entries * 128u * 4u * WAVES_PER_BLOCK;
+            const bool wide_fits = lay.bytes + fixed + wide_stacks <= LDS_BUDGET_BYTES;
+            h->stack_must_wide = max_leaf_ref > 127u || n_triangles > (1u << 24);
+            h->stack_wide = h->stack_must_wide || wide_fits;
+        }
         h->tlas_entries = tlas_entries;
         h->has_tlas = has_tlas;
         h->has_forest = !forest_entries.empty();
@@ -665,7 +674,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "tlas") {
         h->use_tlas = value ? 1 : 0;
     } else if (n == "stack_wide") {
-        h->force_stack_wide = value ? 1 : 0;
+        if (value < -1 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "stack_wide must be -1 (auto), 0 or 1");
+        h->force_stack_wide = value;
     } else if (n == "forest") {
         h->use_forest = value ? 1 : 0;
     } else if (n == "tlas_min") {
@@ -729,7 +739,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.n_textures = h->n_textures;
     a.stack_entries = h->stack_entries;
     a.tlas_entries = h->tlas_entries;
-    a.stack_wide = (h->stack_wide || h->force_stack_wide) ? 1u : 0u;
+    a.stack_wide = (h->stack_must_wide || (h->force_stack_wide < 0 ? h->stack_wide : h->force_stack_wide != 0)) ? 1u : 0u;
     a.n_items = h->n_items;
     a.strip_rank = rank;
     a.strip_world = world;

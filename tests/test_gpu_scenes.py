@@ -240,13 +240,13 @@ def dragon_arrays(rt):
     return rt.SceneArrays.from_scene(sc)
 
 
-@pytest.mark.parametrize("knobs", [{"forest": 0}, {"stack_wide": 1}, {"pixel_cache": 0}, {"pixel_cache": 2},
+@pytest.mark.parametrize("knobs", [{"forest": 0}, {"stack_wide": 1}, {"stack_wide": 0}, {"pixel_cache": 0}, {"pixel_cache": 2},
                                    {"forest": 0, "stack_wide": 1, "pixel_cache": 2}],
                          ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
 def test_tuning_knobs_do_not_change_the_bits(rt, oracle, tracer, cornell, dragon_arrays, knobs):
     """rt_set_option's contract: results never depend on the knobs (forest items, stack entry
     width, memo placement) -- on the LDS-resident Cornell scene and the global-memory dragon scene."""
-    defaults = {"forest": 1, "stack_wide": 0, "pixel_cache": 1}
+    defaults = {"forest": 1, "stack_wide": -1, "pixel_cache": 1}
     try:
         for name, value in knobs.items():
             tracer.set_option(name, value)
