@@ -769,9 +769,14 @@ enum : uint32_t {
 DEV f4 sample_texture(const RenderArgs& a, int index, float u, float v) {
     float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (index >= 0 && (uint32_t)index < a.n_textures) {
-        const DTexture t = a.textures[index];
-        rtm::TexView tv{t.rgba8, t.width, t.height};
-        rtm::sample_bilinear(tv, a.srgb_lut, u, v, out);
+        // global-address-space pointers: global_load, not flat_load
+        typedef const __attribute__((address_space(1))) uint32_t* GWords;
+        typedef const __attribute__((address_space(1))) float* GFloats;
+        const DTexture* tp = a.textures + index;
+        const uint8_t* base = tp->rgba8;
+        const uint32_t w = tp->width, h = tp->height;
+        if (w != 0u && h != 0u && base != nullptr)
+            rtm::sample_bilinear_words((GWords)(const void*)base, w, h, (GFloats)(const void*)a.srgb_lut, u, v, out);
     }
     return f4{out[0], out[1], out[2], out[3]};
 }

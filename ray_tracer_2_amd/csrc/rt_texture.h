@@ -31,13 +31,13 @@ RT_HD int wrap_repeat(int i, int n) {
 
 RT_HD float floor_(float x) { return __builtin_floorf(x); }
 
-RT_HD void sample_bilinear(const TexView& t, const float* srgb_lut, float u, float v, float out[4]) {
-    if (t.width == 0 || t.height == 0 || t.rgba8 == nullptr) {
-        out[0] = out[1] = out[2] = out[3] = 0.0f;
-        return;
-    }
-    float px = u * (float)t.width - 0.5f;
-    float py = v * (float)t.height - 0.5f;
+// WP: pointer to 32-bit texels (one RGBA8 texel per word, R in the low byte), LP: pointer to the
+// 256-entry sRGB table.  Templates so that the kernel can pass global-address-space pointers
+// (global_load instead of flat_load); the oracle passes plain pointers.
+template <class WP, class LP>
+RT_HD void sample_bilinear_words(WP texels, uint32_t width, uint32_t height, LP srgb_lut, float u, float v, float out[4]) {
+    float px = u * (float)width - 0.5f;
+    float py = v * (float)height - 0.5f;
     float fx0 = floor_(px), fy0 = floor_(py);
     float fx = px - fx0, fy = py - fy0;
     // NaN / huge coordinates: clamp the integer part so the conversion is defined
@@ -46,29 +46,38 @@ RT_HD void sample_bilinear(const TexView& t, const float* srgb_lut, float u, flo
     if (!(fy0 > -1.0e9f)) fy0 = -1.0e9f;
     if (!(fy0 < 1.0e9f)) fy0 = 1.0e9f;
     int ix = (int)fx0, iy = (int)fy0;
-    int x0 = wrap_repeat(ix, (int)t.width), x1 = wrap_repeat(ix + 1, (int)t.width);
-    int y0 = wrap_repeat(iy, (int)t.height), y1 = wrap_repeat(iy + 1, (int)t.height);
-    const uint8_t* p00 = t.rgba8 + ((size_t)y0 * t.width + x0) * 4;
-    const uint8_t* p10 = t.rgba8 + ((size_t)y0 * t.width + x1) * 4;
-    const uint8_t* p01 = t.rgba8 + ((size_t)y1 * t.width + x0) * 4;
-    const uint8_t* p11 = t.rgba8 + ((size_t)y1 * t.width + x1) * 4;
+    int x0 = wrap_repeat(ix, (int)width), x1 = wrap_repeat(ix + 1, (int)width);
+    int y0 = wrap_repeat(iy, (int)height), y1 = wrap_repeat(iy + 1, (int)height);
+    const uint32_t t00 = texels[(size_t)y0 * width + x0], t10 = texels[(size_t)y0 * width + x1];
+    const uint32_t t01 = texels[(size_t)y1 * width + x0], t11 = texels[(size_t)y1 * width + x1];
     for (int c = 0; c < 4; ++c) {
+        const uint32_t b00 = (t00 >> (8 * c)) & 255u, b10 = (t10 >> (8 * c)) & 255u;
+        const uint32_t b01 = (t01 >> (8 * c)) & 255u, b11 = (t11 >> (8 * c)) & 255u;
         float a, b, cc, d;
         if (c < 3) {
-            a = srgb_lut[p00[c]];
-            b = srgb_lut[p10[c]];
-            cc = srgb_lut[p01[c]];
-            d = srgb_lut[p11[c]];
+            a = srgb_lut[b00];
+            b = srgb_lut[b10];
+            cc = srgb_lut[b01];
+            d = srgb_lut[b11];
         } else {
-            a = (float)p00[c] / 255.0f;
-            b = (float)p10[c] / 255.0f;
-            cc = (float)p01[c] / 255.0f;
-            d = (float)p11[c] / 255.0f;
+            a = (float)b00 / 255.0f;
+            b = (float)b10 / 255.0f;
+            cc = (float)b01 / 255.0f;
+            d = (float)b11 / 255.0f;
         }
         float top = a * (1.0f - fx) + b * fx;
         float bot = cc * (1.0f - fx) + d * fx;
         out[c] = top * (1.0f - fy) + bot * fy;
     }
+}
+
+// (texture storage is 4-byte aligned on both sides: hipMalloc / numpy arrays of whole texels)
+RT_HD void sample_bilinear(const TexView& t, const float* srgb_lut, float u, float v, float out[4]) {
+    if (t.width == 0 || t.height == 0 || t.rgba8 == nullptr) {
+        out[0] = out[1] = out[2] = out[3] = 0.0f;
+        return;
+    }
+    sample_bilinear_words(reinterpret_cast<const uint32_t*>(t.rgba8), t.width, t.height, srgb_lut, u, v, out);
 }
 
 }  // namespace rtm
