@@ -240,6 +240,86 @@ def dragon_arrays(rt):
     return rt.SceneArrays.from_scene(sc)
 
 
+def _random_scene(rt, seed):
+    """A seeded random scene: boxes/blobs of random triangles in several transform groups (so forest
+    items, singles and root-leaf meshes all occur), random materials (diffuse, glossy, glass, emissive,
+    textured), spheres, sometimes depth of field."""
+    rng = np.random.default_rng(seed)
+    sc = rt.Scene()
+    dof = seed % 3 == 0
+    sc.set_camera(tuple(rng.uniform(-0.5, 0.5, 3) + (0, 1.0, 4.0)), (0, 0.6, 0), fov=float(rng.uniform(40, 80)),
+                  **({"defocus_strength": float(rng.uniform(5, 60)), "diverge_strength": float(rng.uniform(0.2, 1.5))} if dof else {}))
+    tex = (rng.integers(0, 256, (8, 8, 4), dtype=np.uint8))
+    ti = sc.add_texture_rgba8(tex)
+
+    def mat():
+        kind = rng.integers(0, 5)
+        col = tuple(rng.uniform(0.2, 1.0, 3)) + (1.0,)
+        if kind == 0:
+            return rt.material(color=col, smoothness=0.0)
+        if kind == 1:
+            return rt.material(color=col, specular_color=tuple(rng.uniform(0.5, 1, 3)) + (1.0,), smoothness=float(rng.uniform(0.3, 1)),
+                               specular=float(rng.uniform(0, 1)))
+        if kind == 2:
+            return rt.material(color=col, flag=1, ior=float(rng.uniform(1.1, 1.8)), smoothness=float(rng.uniform(0.6, 1)),
+                               specular=float(rng.uniform(0.5, 1)), absorption=tuple(rng.uniform(0, 0.4, 3)) + (0.0,),
+                               absorption_strength=float(rng.uniform(0, 2)))
+        if kind == 3:
+            return rt.material(color=col, emission_color=tuple(rng.uniform(0.5, 1, 3)) + (1.0,), emission_strength=float(rng.uniform(1, 8)))
+        return rt.material(color=col, flag=2, diffuse_index=ti)
+
+    def blob(n_tris, centre, size):
+        verts, idx = [], []
+        for t in range(n_tris):
+            c = centre + rng.uniform(-size, size, 3)
+            tri = c + rng.uniform(-0.35 * size, 0.35 * size, (3, 3))
+            n = np.cross(tri[1] - tri[0], tri[2] - tri[0])
+            n = n / (np.linalg.norm(n) + 1e-12)
+            for k in range(3):
+                verts.append([*tri[k], *n, float(rng.uniform()), float(rng.uniform())])
+            idx += [3 * t, 3 * t + 1, 3 * t + 2]
+        return verts, idx
+
+    floor = [[-1, 0, -1, 0, 1, 0, 0, 0], [1, 0, -1, 0, 1, 0, 1, 0], [1, 0, 1, 0, 1, 0, 1, 1], [-1, 0, 1, 0, 1, 0, 0, 1]]
+    sc.add_mesh_from_data(floor, [2, 1, 0, 3, 2, 0], xform=rt.transform(scale=(5, 1, 5)), mat=rt.material(color=(0.8, 0.8, 0.8, 1)))
+    for g in range(int(rng.integers(1, 4))):      # transform groups
+        q = rng.normal(size=4)
+        q = q / np.linalg.norm(q)
+        xf = None if g == 0 else rt.transform(pos=tuple(rng.uniform(-1, 1, 3) + (0, 0.8, 0)), rot=tuple(q),
+                                              scale=tuple(rng.uniform(0.5, 1.5, 3)))
+        for m in range(int(rng.integers(1, 5))):  # meshes sharing it
+            v, i = blob(int(rng.integers(1, 40)), rng.uniform(-1.2, 1.2, 3) * (1, 0.4, 1) + (0, 0.7, 0), float(rng.uniform(0.2, 0.6)))
+            sc.add_mesh_from_data(v, i, xform=xf, mat=mat())
+    for k in range(int(rng.integers(0, 3))):
+        sc.add_sphere(tuple(rng.uniform(-1.5, 1.5, 3) * (1, 0.3, 1) + (0, 0.6, 0)), float(rng.uniform(0.2, 0.6)), mat())
+    sc.build()
+    return rt.SceneArrays.from_scene(sc)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes(rt, oracle, tracer, seed):
+    """Seeded random scenes, both kernel variants, with the traversal counters."""
+    arrays = _random_scene(rt, seed)
+    p = rt.make_params(96, 54, 5, 3, skybox=1, frames=0)
+    ref, st = oracle.render(p, arrays)
+    tracer.load_scene(arrays)
+    try:
+        for variant in (0, 1):
+            tracer.set_option("kernel_variant", variant)
+            tracer.set_counters(True)
+            tracer.reset_timing()
+            tracer.render(p)
+            gpu = tracer.read_image(96, 54)
+            s = tracer.stats()
+            tracer.set_counters(False)
+            assert same(gpu, ref), (seed, variant)
+            assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests), (seed, variant)
+            tracer.render(p)
+            assert same(tracer.read_image(96, 54), ref), (seed, variant, "product kernel")
+    finally:
+        tracer.set_option("kernel_variant", -1)
+
+
 @pytest.mark.parametrize("knobs", [{"forest": 0}, {"stack_wide": 1}, {"stack_wide": 0}, {"pixel_cache": 0}, {"pixel_cache": 2},
                                    {"forest": 0, "stack_wide": 1, "pixel_cache": 2}],
                          ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
