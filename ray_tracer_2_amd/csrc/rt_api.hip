@@ -65,6 +65,9 @@ struct rt_handle {
     bool history_valid = false;
     uint32_t hist_w = 0, hist_h = 0, hist_rank = 0, hist_world = 0;
     int tile_feedback = 1;
+    int tile_feedback_period = 8;  // frames an order is kept before it is refreshed
+    bool have_order = false, costs_ready = false;
+    uint32_t order_age = 0;
     uint32_t persistent_blocks = 0;
     float* srgb_lut = nullptr;
     // scene
@@ -226,6 +229,7 @@ int rt_create(int device_ordinal, uint32_t max_width, uint32_t max_height, rt_ha
     HIP_TRY(h, hipMalloc((void**)&h->counters, sizeof(Counters)));
     HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(Counters), h->stream));
     HIP_TRY(h, hipMalloc((void**)&h->work_counters, 64 * sizeof(uint32_t)));
+    HIP_TRY(h, hipMemsetAsync(h->work_counters, 0, 64 * sizeof(uint32_t), h->stream));
     h->tile_capacity = ((max_width + 7) / 8) * ((max_height + 7) / 8 + 1);
     for (int k = 0; k < 2; ++k) HIP_TRY(h, hipMalloc((void**)&h->tile_cost[k], (size_t)h->tile_capacity * sizeof(uint32_t)));
     HIP_TRY(h, hipMalloc((void**)&h->tile_order, (size_t)h->tile_capacity * sizeof(uint32_t)));
@@ -662,6 +666,10 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "tile_feedback") {
         h->tile_feedback = value ? 1 : 0;
         h->history_valid = false;
+    } else if (n == "tile_feedback_period") {
+        if (value < 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "tile_feedback_period must be >= 1");
+        h->tile_feedback_period = value;
+        h->history_valid = false;
     } else if (n == "vote_eighths") {
         if (value < 0 || value > 8) return fail(h, RT_ERR_INVALID_ARGUMENT, "vote_eighths must be 0..8");
         h->vote_eighths = value;
@@ -783,28 +791,42 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         a.pixel_cache = 2;
         a.pixel_cache_mem = h->pixel_cache_mem;
     }
-    // a fresh tile counter per launch (ring of 64: launches on one stream are ordered)
+    // a fresh tile counter per launch: a ring of 64, zeroed in one go each time it wraps (launches on
+    // one stream are ordered, so every earlier user of the ring is done by then)
     h->work_slot = (h->work_slot + 1) & 63u;
+    if (h->work_slot == 0u) HIP_TRY(h, hipMemsetAsync(h->work_counters, 0, 64 * sizeof(uint32_t), h->stream));
     a.work_counter = h->work_counters + h->work_slot;
-    HIP_TRY(h, hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), h->stream));
-    // Tile-cost feedback (path-trace frames only): schedule this frame's tiles by the rays each
-    // took in the previous frame of the same shape; record this frame's for the next.
+    // Tile-cost feedback (persistent kernel, path-trace frames only): the tiles are handed out in the
+    // order of the rays each took in an earlier frame of the same shape, heaviest first.  Progressive
+    // accumulation re-renders the same view, so an order stays good: it is refreshed every
+    // `tile_feedback_period` frames (costs are recorded in the frame before a refresh), not every frame.
     const uint32_t n_tiles = a.tiles_x * a.tiles_y;
     a.tile_order = nullptr;
     a.tile_cost = nullptr;
-    if (h->tile_feedback && params->debug_flag == 0 && n_tiles <= h->tile_capacity && n_tiles > 0) {
+    if (h->tile_feedback && params->debug_flag == 0 && n_tiles <= h->tile_capacity && n_tiles > 0 && a.kernel_variant == 0) {
         const bool same_shape = h->history_valid && h->hist_w == params->width && h->hist_h == params->height &&
                                 h->hist_rank == rank && h->hist_world == world;
-        if (same_shape && a.kernel_variant == 0) {
+        if (!same_shape) {
+            h->have_order = false;
+            h->costs_ready = false;
+        }
+        if (h->costs_ready && (!h->have_order || h->order_age >= (uint32_t)h->tile_feedback_period)) {
             const long long per_tile = 64ll * (params->rays_per_pixel > 0 ? params->rays_per_pixel : 0) *
                                        (params->number_of_bounces >= 0 ? params->number_of_bounces + 1 : 0);
             const uint32_t max_cost = per_tile > 0xffffffffll ? 0xffffffffu : (uint32_t)per_tile;
             HIP_TRY(h, launch_tile_order(h->tile_cost[h->cost_slot], n_tiles, max_cost, h->tile_order, h->stream));
-            a.tile_order = h->tile_order;
+            h->have_order = true;
+            h->order_age = 0;
+            h->costs_ready = false;
         }
-        h->cost_slot ^= 1;
-        a.tile_cost = h->tile_cost[h->cost_slot];
-        HIP_TRY(h, hipMemsetAsync(a.tile_cost, 0, (size_t)n_tiles * sizeof(uint32_t), h->stream));
+        if (h->have_order) a.tile_order = h->tile_order;
+        if (!h->have_order || h->order_age + 1u >= (uint32_t)h->tile_feedback_period) {
+            h->cost_slot ^= 1;
+            a.tile_cost = h->tile_cost[h->cost_slot];
+            HIP_TRY(h, hipMemsetAsync(a.tile_cost, 0, (size_t)n_tiles * sizeof(uint32_t), h->stream));
+            h->costs_ready = true;
+        }
+        h->order_age += 1;
         h->history_valid = true;
         h->hist_w = params->width;
         h->hist_h = params->height;
