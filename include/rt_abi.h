@@ -325,6 +325,12 @@ int rt_scene_add_texture_rgba8(rt_scene* s, const uint8_t* rgba8, uint32_t w, ui
 /* ≙ BVH::build_per_mesh(meshes, Quality::High) (bvh.rs:152-207);
  * quality: 0 = Low, 1 = High, 2 = Disabled (bvh.rs:126-131). */
 int rt_scene_build(rt_scene* s, int quality);
+/* The same build with the SAH plane searches (find_best_split, src/core/bvh.rs:299-351: the
+ * O(150 n)-per-level part) of meshes with at least `min_triangles` triangles (0 = default 16384)
+ * done on GPU `device`; nodes, node order and triangle order are bit-identical to rt_scene_build's
+ * (evaluate_sah is order-independent: minima, maxima and integer counts).  device = -1 runs the
+ * same level-wise build with the searches on the host (validation).  SURVEY 8(f)-4. */
+int rt_scene_build_device(rt_scene* s, int quality, int device, uint32_t min_triangles);
 
 /* Accessors: pointers stay valid until the scene is modified or destroyed. */
 int rt_scene_get_uniform(const rt_scene* s, rt_scene_uniform* out); /* ≙ Scene::to_uniform */

@@ -14,7 +14,7 @@ PRODUCT_SO = os.path.join(ROOT, "ray_tracer_2_amd", "librt2_mi355x.so")
 ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "librt_oracle.so")
 
 PRODUCT_SOURCES = [
-    "rt_kernel.hip", "rt_api.hip", "host/obj_loader.cpp", "host/bvh.cpp", "host/scene.cpp",
+    "rt_kernel.hip", "rt_api.hip", "rt_bvh_search.hip", "host/obj_loader.cpp", "host/bvh.cpp", "host/scene.cpp",
     "host/png_decode.cpp", "host/scene_capi.cpp", "host/ray_tracer.cpp",
 ]
 PRODUCT_HEADERS = [

@@ -3,6 +3,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <utility>
 
@@ -210,6 +211,195 @@ BvhResult bvh_build(const std::vector<Vertex>& vertices, const std::vector<uint3
         out.triangles[k] = p;
     }
     out.nodes = std::move(b.nodes);
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// level-wise build
+// ---------------------------------------------------------------------------------------------
+namespace {
+std::vector<BuildTri> make_build_tris(const std::vector<Vertex>& vertices, const std::vector<uint32_t>& indices) {
+    size_t n_tris = indices.size() / 3;
+    std::vector<BuildTri> tris(n_tris);
+    for (size_t j = 0; j < n_tris; ++j) {  // bvh.rs:221-242
+        size_t i = j * 3;
+        Vec3 v1 = vertices[indices[i]].pos, v2 = vertices[indices[i + 1]].pos, v3 = vertices[indices[i + 2]].pos;
+        BuildTri t;
+        t.centroid = ((v1 + v2) + v3) * (1.0f / 3.0f);
+        t.mx = vmax(v1, vmax(v2, v3));
+        t.mn = vmin(v1, vmin(v2, v3));
+        t.i = (int32_t)i;
+        tris[j] = t;
+    }
+    return tris;
+}
+}  // namespace
+
+std::vector<float> bvh_search_data(const std::vector<Vertex>& vertices, const std::vector<uint32_t>& indices) {
+    std::vector<BuildTri> tris = make_build_tris(vertices, indices);
+    std::vector<float> out(tris.size() * 9);
+    for (size_t j = 0; j < tris.size(); ++j) {
+        float* o = out.data() + j * 9;
+        o[0] = tris[j].centroid.x; o[1] = tris[j].centroid.y; o[2] = tris[j].centroid.z;
+        o[3] = tris[j].mn.x; o[4] = tris[j].mn.y; o[5] = tris[j].mn.z;
+        o[6] = tris[j].mx.x; o[7] = tris[j].mx.y; o[8] = tris[j].mx.z;
+    }
+    return out;
+}
+
+LevelSearch make_host_level_search(const float* tri9, size_t n_tris) {
+    std::vector<float> data(tri9, tri9 + n_tris * 9);
+    return [data](const uint32_t* order, size_t n, const std::vector<SplitQuery>& qs, std::vector<SplitResult>& out) {
+        Builder b;
+        b.quality = Quality::High;
+        b.tris.resize(n);
+        for (size_t p = 0; p < n; ++p) {
+            const float* d = data.data() + (size_t)order[p] * 9;
+            b.tris[p].centroid = Vec3{d[0], d[1], d[2]};
+            b.tris[p].mn = Vec3{d[3], d[4], d[5]};
+            b.tris[p].mx = Vec3{d[6], d[7], d[8]};
+            b.tris[p].i = (int32_t)order[p] * 3;
+        }
+        out.resize(qs.size());
+        for (size_t k = 0; k < qs.size(); ++k) {
+            rt_node node{};
+            memcpy(node.aabb_min, qs[k].aabb_min, 12);
+            memcpy(node.aabb_max, qs[k].aabb_max, 12);
+            node.count = qs[k].count;
+            int axis = 0;
+            float pos = 0.0f;
+            out[k].cost = b.find_best_split(node, axis, pos, qs[k].start, qs[k].count);
+            out[k].axis = axis;
+            out[k].pos = pos;
+        }
+    };
+}
+
+BvhResult bvh_build_levels(const std::vector<Vertex>& vertices, const std::vector<uint32_t>& indices, Quality quality,
+                           const LevelSearch& search) {
+    if (quality != Quality::High || !search) return bvh_build(vertices, indices, quality);
+    BvhResult out;
+    size_t n_tris = indices.size() / 3;
+    if (n_tris == 0) return out;
+    Builder b;
+    b.quality = quality;
+    b.tris = make_build_tris(vertices, indices);
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};  // bvh.rs:244-250
+    for (const BuildTri& t : b.tris) Builder::fit_bounds(mn, mx, t);
+    // nodes in breadth-first order while building; renumbered to the reference's order at the end
+    struct Open { uint32_t node, start, count, depth; };
+    std::vector<rt_node> nodes;
+    rt_node root{};
+    for (int a = 0; a < 3; ++a) {
+        root.aabb_min[a] = mn[a];
+        root.aabb_max[a] = mx[a];
+    }
+    root.count = (uint32_t)n_tris;
+    nodes.push_back(root);
+    std::vector<Open> level{Open{0, 0, (uint32_t)n_tris, 0}};
+    std::vector<uint32_t> order(n_tris);
+    std::vector<SplitQuery> qs;
+    std::vector<SplitResult> rs;
+    while (!level.empty()) {
+        // find_best_split of every node of the level (count <= 1: infinite cost, bvh.rs:301-303)
+        qs.clear();
+        std::vector<uint32_t> asked;
+        for (uint32_t k = 0; k < level.size(); ++k) {
+            if (level[k].count <= 1 || level[k].depth >= 32) continue;  // (depth 32 never splits: :384)
+            SplitQuery q;
+            q.start = level[k].start;
+            q.count = level[k].count;
+            memcpy(q.aabb_min, nodes[level[k].node].aabb_min, 12);
+            memcpy(q.aabb_max, nodes[level[k].node].aabb_max, 12);
+            qs.push_back(q);
+            asked.push_back(k);
+        }
+        if (qs.empty()) break;
+        for (size_t p = 0; p < n_tris; ++p) order[p] = (uint32_t)(b.tris[p].i / 3);
+        search(order.data(), n_tris, qs, rs);
+        std::vector<Open> next;
+        for (size_t j = 0; j < asked.size(); ++j) {
+            const Open o = level[asked[j]];
+            const float parent_cost = Builder::node_cost(nodes[o.node]);
+            const int axis = rs[j].axis;
+            const float split_pos = rs[j].pos;
+            if (!(rs[j].cost < parent_cost)) continue;  // bvh.rs:384
+            // the partition of subdivide (bvh.rs:385-400), operation for operation
+            float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            float rmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, rmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            size_t left_count = 0;
+            for (size_t i = o.start; i < (size_t)o.start + o.count; ++i) {
+                const BuildTri& t = b.tris[i];
+                if (t.centroid[axis] < split_pos) {
+                    Builder::fit_bounds(lmn, lmx, t);
+                    std::swap(b.tris[o.start + left_count], b.tris[i]);
+                    left_count += 1;
+                } else {
+                    Builder::fit_bounds(rmn, rmx, t);
+                }
+            }
+            rt_node l{}, r{};
+            for (int a = 0; a < 3; ++a) {
+                l.aabb_min[a] = lmn[a];
+                l.aabb_max[a] = lmx[a];
+                r.aabb_min[a] = rmn[a];
+                r.aabb_max[a] = rmx[a];
+            }
+            l.first = o.start;
+            l.count = (uint32_t)left_count;
+            r.first = o.start + (uint32_t)left_count;
+            r.count = o.count - (uint32_t)left_count;
+            const uint32_t li = (uint32_t)nodes.size();
+            nodes.push_back(l);
+            nodes.push_back(r);
+            nodes[o.node].left = li;
+            nodes[o.node].right = li + 1;
+            nodes[o.node].count = 0;
+            next.push_back(Open{li, l.first, l.count, o.depth + 1});
+            next.push_back(Open{li + 1, r.first, r.count, o.depth + 1});
+        }
+        level.swap(next);
+    }
+    // The reference numbers nodes in the order subdivide creates them: both children of a node,
+    // then the left subtree, then the right one (bvh.rs:402-468).
+    std::vector<uint32_t> renum(nodes.size(), 0xffffffffu);
+    std::vector<uint32_t> stack{0u};
+    uint32_t next_index = 1;
+    renum[0] = 0;
+    while (!stack.empty()) {
+        const uint32_t n = stack.back();
+        stack.pop_back();
+        if (nodes[n].count == 0 && (nodes[n].left != 0 || nodes[n].right != 0)) {
+            renum[nodes[n].left] = next_index;
+            renum[nodes[n].right] = next_index + 1;
+            next_index += 2;
+            stack.push_back(nodes[n].right);
+            stack.push_back(nodes[n].left);
+        }
+    }
+    out.nodes.resize(nodes.size());
+    for (size_t n = 0; n < nodes.size(); ++n) {
+        rt_node v = nodes[n];
+        if (v.count == 0 && (v.left != 0 || v.right != 0)) {
+            v.left = renum[v.left];
+            v.right = renum[v.right];
+        }
+        out.nodes[renum[n]] = v;
+    }
+    out.triangles.resize(n_tris);
+    for (size_t k = 0; k < n_tris; ++k) {  // bvh.rs:278-287
+        const BuildTri& t = b.tris[k];
+        const Vertex& a = vertices[indices[t.i]];
+        const Vertex& bb = vertices[indices[t.i + 1]];
+        const Vertex& c = vertices[indices[t.i + 2]];
+        rt_packed_triangle p;
+        put3(p.v1, a.pos); put3(p.v2, bb.pos); put3(p.v3, c.pos);
+        put3(p.n1, a.normal); put3(p.n2, bb.normal); put3(p.n3, c.normal);
+        p.uv10 = a.uv[0]; p.uv11 = a.uv[1];
+        p.uv20 = bb.uv[0]; p.uv21 = bb.uv[1];
+        p.uv30 = c.uv[0]; p.uv31 = c.uv[1];
+        out.triangles[k] = p;
+    }
     return out;
 }
 

@@ -281,13 +281,22 @@ bool AssetManager::load_model(const std::string& path, const Transform& transfor
     return true;
 }
 
-void Scene::build_per_mesh(Quality q) {  // bvh.rs:152-207
+void Scene::build_per_mesh(Quality q, int device, size_t device_min_tris) {  // bvh.rs:152-207
     triangles.clear();
     nodes.clear();
     mesh_uniforms.clear();
     size_t triangle_offset = 0, node_offset = 0;
     for (const MeshInstance& mi : meshes) {
-        BvhResult r = bvh_build(mi.data->vertices, mi.data->indices, q);
+        BvhResult r;
+        if (device >= -1 && q == Quality::High && mi.data->indices.size() / 3 >= device_min_tris) {
+            // (device -1: the level-wise build with the searches on the host, for validation)
+            const std::vector<float> tri9 = bvh_search_data(mi.data->vertices, mi.data->indices);
+            r = bvh_build_levels(mi.data->vertices, mi.data->indices, q,
+                                 device >= 0 ? make_device_level_search(device, tri9.data(), tri9.size() / 9)
+                                             : make_host_level_search(tri9.data(), tri9.size() / 9));
+        } else {
+            r = bvh_build(mi.data->vertices, mi.data->indices, q);
+        }
         Mat4 m2w = mi.transform.to_matrix();
         Mat4 w2m = mat4_inverse(m2w);
         rt_mesh_uniform u{};

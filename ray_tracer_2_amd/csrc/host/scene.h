@@ -80,7 +80,9 @@ class Scene {  // scene.rs:148-156
     bool built_bvh = false;
 
     // ≙ BVH::build_per_mesh (bvh.rs:152-207)
-    void build_per_mesh(Quality q);
+    // device >= 0: meshes of at least `device_min_tris` triangles have their SAH searches done on that
+    // GPU (csrc/rt_bvh_search.hip); the result is the same, bit for bit
+    void build_per_mesh(Quality q, int device = -2, size_t device_min_tris = 16384);  // -2: plain bvh_build
     // ≙ Scene::to_uniform (scene.rs:985-1001)
     rt_scene_uniform to_uniform() const;
     // n x n barycentric split of every mesh triangle (stand-in geometry)

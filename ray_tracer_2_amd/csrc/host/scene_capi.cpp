@@ -191,6 +191,25 @@ int rt_scene_build(rt_scene* s, int quality) {
     return RT_OK;
 }
 
+int rt_scene_build_device(rt_scene* s, int quality, int device, uint32_t min_triangles) {
+    if (!s || quality < 0 || quality > 2 || device < -1) return RT_ERR_INVALID_ARGUMENT;
+    if (s->scene.meshes.size() > RT_MAX_MESHES) {
+        s->err = "more than 400 meshes";
+        return RT_ERR_CAPACITY;
+    }
+    try {
+        s->scene.build_per_mesh((Quality)quality, device, min_triangles ? (size_t)min_triangles : 16384);
+    } catch (const std::exception& e) {
+        s->err = e.what();
+        return strncmp(e.what(), "HIP", 3) == 0 ? RT_ERR_DEVICE : RT_ERR_OUT_OF_MEMORY;
+    }
+    if (s->scene.triangles.size() > RT_MAX_TRIANGLES || s->scene.nodes.size() > RT_MAX_NODES) {
+        s->err = "scene exceeds the triangle/node capacity";
+        return RT_ERR_CAPACITY;
+    }
+    return RT_OK;
+}
+
 int rt_scene_subdivide_meshes(rt_scene* s, uint32_t n) {
     if (!s || n == 0) return RT_ERR_INVALID_ARGUMENT;
     try {

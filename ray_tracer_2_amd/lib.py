@@ -20,7 +20,7 @@ EXPORTS = [
     "rt_last_error", "rt_destroy", "rt_version", "rt_device_count", "rt_abi_sizes",
     "rt_scene_load_builtin", "rt_scene_create", "rt_scene_set_camera", "rt_transform_cam",
     "rt_scene_add_sphere", "rt_scene_add_obj", "rt_scene_add_mesh_data",
-    "rt_scene_add_texture_rgba8", "rt_scene_build", "rt_scene_get_uniform",
+    "rt_scene_add_texture_rgba8", "rt_scene_build", "rt_scene_build_device", "rt_scene_get_uniform",
     "rt_scene_num_spheres", "rt_scene_num_meshes", "rt_scene_num_triangles", "rt_scene_num_nodes",
     "rt_scene_num_textures", "rt_scene_spheres", "rt_scene_meshes", "rt_scene_triangles",
     "rt_scene_nodes", "rt_scene_get_texture", "rt_scene_mesh_label", "rt_scene_mesh_data", "rt_scene_num_mesh_instances", "rt_scene_last_error",
@@ -83,6 +83,7 @@ def load():
         "rt_scene_add_mesh_data": (i32, [vp, vp, u32, vp, u32, P(A.Transform), P(A.Material)]),
         "rt_scene_add_texture_rgba8": (i32, [vp, vp, u32, u32]),
         "rt_scene_build": (i32, [vp, i32]),
+        "rt_scene_build_device": (i32, [vp, i32, i32, u32]),
         "rt_scene_get_uniform": (i32, [vp, P(A.SceneUniform)]),
         "rt_scene_num_spheres": (u32, [vp]),
         "rt_scene_num_meshes": (u32, [vp]),

@@ -100,8 +100,11 @@ class Scene:
     def subdivide_meshes(self, n):
         self._check(self._L.rt_scene_subdivide_meshes(self._p, n))
 
-    def build(self, quality=1):
-        self._check(self._L.rt_scene_build(self._p, quality))
+    def build(self, quality=1, device=None, min_triangles=0):
+        if device is None:
+            self._check(self._L.rt_scene_build(self._p, quality))
+        else:  # SAH searches of large meshes on the GPU; same result
+            self._check(self._L.rt_scene_build_device(self._p, quality, int(device), int(min_triangles)))
 
     # ---- the arrays the hot path consumes -----------------------------
     def uniform(self):

@@ -46,7 +46,7 @@ DRAGON_MATERIAL = dict(color=(0.96078, 0.11372, 0.4039, 1.0), emission_color=(1,
                        specular_color=(1, 1, 1, 1), smoothness=0.8, specular=0.015, ior=0.0)
 
 
-def cornell_dragon(cornell_raw, dragon_raw, subdivide=3):
+def cornell_dragon(cornell_raw, dragon_raw, subdivide=3, device=None):
     """BASELINE config 3 stand-in: the missing Dragon_80K.obj is replaced by
     assets/dragon.obj (8,712 triangles) with every triangle split n x n (n = 3 -> 78,408
     triangles), inside the Cornell box, with room_2's dragon material."""
@@ -59,7 +59,7 @@ def cornell_dragon(cornell_raw, dragon_raw, subdivide=3):
     sc = cornell_from_raw(cornell_raw)
     for _label, v, idx, t, m in dragon.raw_meshes():
         sc.add_mesh_from_data(v, idx, xform=t, mat=m)
-    sc.build()
+    sc.build(device=device)   # device: SAH searches of the big mesh on that GPU (same result)
     return sc
 
 

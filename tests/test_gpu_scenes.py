@@ -498,3 +498,34 @@ def test_config4_sponza_standin(rt, oracle, tracer):
         pd = rt.make_params(192, 108, 4, 1, debug_flag=dbg, debug_scale=500)
         gpu, ref, _, _ = render_both(rt, oracle, tracer, a, pd)
         assert same(gpu, ref), dbg
+
+
+@pytest.mark.parametrize("case", ["cornell", "dragon_x9", "soup"])
+def test_gpu_sah_search_builds_the_same_bvh(rt, case):
+    """the BVH build with find_best_split on the GPU (rt_scene_build_device) against the
+    host builder: same nodes, same node numbering, same triangle order, bit for bit."""
+    from ray_tracer_2_amd import scenes
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if case == "cornell":
+        sc = scenes.cornell_from_raw(scenes.load_raw_meshes(os.path.join(g, "cornell_raw.npz")))
+    elif case == "dragon_x9":
+        sc = rt.Scene()
+        for _label, v, idx, _t, _m in scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")):
+            sc.add_mesh_from_data(v, idx)
+        sc.subdivide_meshes(3)   # 78,408 triangles: multi-chunk nodes at the top, single-chunk below
+    else:
+        rng = np.random.default_rng(5)
+        sc = rt.Scene()
+        for n in (1, 2, 3, 17, 700, 5000):
+            tri = rng.uniform(-1, 1, (n, 1, 3)) + rng.uniform(-0.2, 0.2, (n, 3, 3))
+            tri[n // 2:] = np.round(tri[n // 2:], 1)   # ties: equal centroids, zero-extent axes
+            v = np.concatenate([tri.reshape(-1, 3), np.tile([0, 1, 0, 0, 0], (3 * n, 1))], axis=1)
+            sc.add_mesh_from_data(v, np.arange(3 * n))
+
+    def built(**kw):
+        sc.build(**kw)
+        a = rt.SceneArrays.from_scene(sc)
+        return a.nodes.tobytes(), a.triangles.tobytes(), a.meshes.tobytes()
+
+    ref = built()
+    assert built(device=0, min_triangles=1) == ref

@@ -214,3 +214,32 @@ def test_png_decoder_and_texture_flip(rt, tmp_path):
         sc.build()
         m = sc.meshes()["material"][0]
         assert m["flag"] == 2 and m["diffuse_index"] == 0 and m["normal_index"] == -1
+
+
+def _built_arrays(rt, sc, **kw):
+    sc.build(**kw)
+    a = rt.SceneArrays.from_scene(sc)
+    return a.nodes.tobytes(), a.triangles.tobytes(), a.meshes.tobytes()
+
+
+@pytest.mark.parametrize("case", ["cornell", "dragon", "soup"])
+def test_level_wise_bvh_build_is_identical(rt, case):
+    """bvh_build_levels (breadth-first, searches in batches -- the host stand-in of the GPU search) must
+    reproduce bvh_build: same nodes, same node numbering, same triangle order, bit for bit."""
+    from ray_tracer_2_amd import scenes
+    if case == "cornell":
+        sc = scenes.cornell_from_raw(scenes.load_raw_meshes(os.path.join(GOLDEN, "cornell_raw.npz")))
+    elif case == "dragon":
+        sc = rt.Scene()
+        for _label, v, idx, _t, _m in scenes.load_raw_meshes(os.path.join(GOLDEN, "dragon_raw.npz")):
+            sc.add_mesh_from_data(v, idx)
+    else:
+        rng = np.random.default_rng(5)
+        sc = rt.Scene()
+        for n in (1, 2, 3, 17, 700):
+            tri = rng.uniform(-1, 1, (n, 1, 3)) + rng.uniform(-0.2, 0.2, (n, 3, 3))
+            tri[n // 2:] = np.round(tri[n // 2:], 1)   # ties: equal centroids, zero-extent axes
+            v = np.concatenate([tri.reshape(-1, 3), np.tile([0, 1, 0, 0, 0], (3 * n, 1))], axis=1)
+            sc.add_mesh_from_data(v, np.arange(3 * n))
+    ref = _built_arrays(rt, sc)
+    assert _built_arrays(rt, sc, device=-1, min_triangles=1) == ref
