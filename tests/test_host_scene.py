@@ -243,3 +243,14 @@ def test_level_wise_bvh_build_is_identical(rt, case):
             sc.add_mesh_from_data(v, np.arange(3 * n))
     ref = _built_arrays(rt, sc)
     assert _built_arrays(rt, sc, device=-1, min_triangles=1) == ref
+
+
+def test_device_bvh_build_fails_loudly_without_a_gpu(rt):
+    """No silent fallback: asking for the GPU search on a machine without a HIP device is an error."""
+    if rt.load().rt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from ray_tracer_2_amd import scenes
+    sc = scenes.cornell_from_raw(scenes.load_raw_meshes(os.path.join(GOLDEN, "cornell_raw.npz")))
+    with pytest.raises(rt.RtError) as e:
+        sc.build(device=0, min_triangles=1)
+    assert e.value.code == -3   # RT_ERR_DEVICE (include/rt_abi.h)
