@@ -231,13 +231,14 @@ struct DeviceSearch {
     hipStream_t stream = nullptr;
 
     ~DeviceSearch() {
-        hipFree(tri9); hipFree(order); hipFree(queries); hipFree(blocks); hipFree(multis); hipFree(partials); hipFree(results);
-        if (stream) hipStreamDestroy(stream);
+        for (void* p : {(void*)tri9, (void*)order, (void*)queries, (void*)blocks, (void*)multis, (void*)partials, (void*)results})
+            if (p) (void)hipFree(p);
+        if (stream) (void)hipStreamDestroy(stream);
     }
     template <class T>
     void grow(T*& p, size_t& cap, size_t need) {
         if (need <= cap) return;
-        hipFree(p);
+        if (p) (void)hipFree(p);
         p = nullptr;
         cap = need + need / 2 + 16;
         HIP_OK(hipMalloc((void**)&p, cap * sizeof(T)));
