@@ -44,14 +44,17 @@ def hipcc_path():
 
 def build_product(force=False, extra_flags=()):
     srcs = [os.path.join(CSRC, s) for s in PRODUCT_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in PRODUCT_HEADERS]
+    deps = srcs + [os.path.join(CSRC, h) for h in PRODUCT_HEADERS] + [os.path.abspath(__file__)]   # (flags live in this file)
     if not force and not _newer(PRODUCT_SO, deps):
         return PRODUCT_SO
     # -ffp-contract=off: the canonical arithmetic is unfused (every fused
     # operation is an explicit fma in rt_transc.h); division and sqrt stay
     # correctly rounded (hipcc default, no fast-math).
+    # -fno-slp-vectorize: the SLP vectoriser's automatic v_pk_*_f32 packing pays for itself in
+    # v_mov shuffles here (measured: 2.22 -> 2.09 ms on config 2 without it); the packed forms
+    # that do pay (the slab tests) are written out with 2-vectors in rt_kernel.hip.
     cmd = [hipcc_path(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
-           "-fno-fast-math", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
+           "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
            "-I", os.path.join(ROOT, "include"), *extra_flags, *srcs, "-lz", "-o", PRODUCT_SO]
     _run(cmd)
     return PRODUCT_SO

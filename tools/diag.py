@@ -34,7 +34,7 @@ def build_timed():
     if os.path.exists(TIME_SO) and all(os.path.getmtime(TIME_SO) > os.path.getmtime(s) for s in srcs):
         return
     subprocess.run([build.hipcc_path(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
-                    "-fno-fast-math", "-fPIC", "-shared", "-DRT_DIAGT=1", "-I", os.path.join(ROOT, "include"),
+                    "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared", "-DRT_DIAGT=1", "-I", os.path.join(ROOT, "include"),
                     *srcs, "-lz", "-o", TIME_SO], check=True)
 
 
@@ -43,7 +43,7 @@ def build_diag():
     if os.path.exists(DIAG_SO) and all(os.path.getmtime(DIAG_SO) > os.path.getmtime(s) for s in srcs):
         return
     subprocess.run([build.hipcc_path(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
-                    "-fno-fast-math", "-fPIC", "-shared", "-DRT_DIAG=1", "-I", os.path.join(ROOT, "include"),
+                    "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared", "-DRT_DIAG=1", "-I", os.path.join(ROOT, "include"),
                     *srcs, "-lz", "-o", DIAG_SO], check=True)
 
 
