@@ -201,13 +201,15 @@ def main():
             tj = json.load(open(tpath))
             traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
             if "valu_instructions_per_launch" in tj:
-                # the bound that matters: VALU issue.  A SIMD issues one wave64 VALU
-                # instruction per 4 cycles; instruction count and clock come from the same rocprofv3 passes.
+                # the bound that matters: VALU issue.  Peak = the fastest plain VALU
+                # stream measured on this chip (tools/micro/issue_cost.hip: v_mul_f32, 8 waves/SIMD, one
+                # wave64 instruction per 3.0 cycles per SIMD; v_fma/v_min ~4); instruction count and clock
+                # come from the same rocprofv3 passes as the traffic.
                 simds = torch.cuda.get_device_properties(device).multi_processor_count * 4
                 clock = tj.get("shader_clock_ghz", 2.4)
                 rate = tj["valu_instructions_per_launch"] / (kernel_ms * 1e-3) / 1e9
-                valu = {"bound": "valu_issue", "achieved": rate, "peak": simds * clock / 4.0, "unit": "G wave-instructions/s",
-                        "frac": rate / (simds * clock / 4.0), "lane_utilisation": tj.get("valu_lane_utilisation"),
+                valu = {"bound": "valu_issue", "achieved": rate, "peak": simds * clock / 3.0, "unit": "G wave-instructions/s",
+                        "frac": rate / (simds * clock / 3.0), "lane_utilisation": tj.get("valu_lane_utilisation"),
                         "source": tj["source"].replace("FETCH_SIZE / WRITE_SIZE", "SQ_INSTS_VALU / GRBM_GUI_ACTIVE")}
         out = {
             "metric": "Mrays/s", "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
