@@ -88,7 +88,7 @@ constexpr uint32_t SPHERE_BYTES = 16;
 // SIMD.  The render kernels are compiled for that register budget (512 / RT_MIN_WAVES VGPRs) and
 // the LDS budget per workgroup is the CU's 160 KiB divided by it.
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 4
+#define RT_MIN_WAVES 5
 #endif
 constexpr uint32_t BLOCKS_PER_CU = RT_MIN_WAVES;
 constexpr uint32_t LDS_BUDGET_BYTES = 160 * 1024 / BLOCKS_PER_CU;
