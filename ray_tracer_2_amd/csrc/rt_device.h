@@ -97,7 +97,10 @@ constexpr uint32_t WAVES_PER_BLOCK = BLOCK_THREADS / 64;
 // Per-lane state kept in LDS instead of registers (see path_step): the pixel's running sum
 // `total`, 4 floats.  It is touched once per path but would otherwise occupy 4 VGPRs across the
 // whole traversal.
-constexpr uint32_t LANE_STATE_DWORDS = 4;
+#ifndef RT_TOTAL_IN_LDS
+#define RT_TOTAL_IN_LDS 1   // 0 (experiment): the pixel sum stays in registers in every kernel
+#endif
+constexpr uint32_t LANE_STATE_DWORDS = RT_TOTAL_IN_LDS ? 4 : 0;
 // Per-lane primary-ray memo (see path_step): rd, hit record (dst, point, normal, u, v), and
 // one word = mat_off | hit | backface << 1 | ray valid << 2 | hit valid << 3.
 constexpr uint32_t PIXEL_MEMO_DWORDS = 13;

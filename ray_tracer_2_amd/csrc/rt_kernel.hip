@@ -849,7 +849,7 @@ DEV void store_texel(const A& a, uint32_t x, uint32_t out_row, f4 cur) {
 // offsets, so the whole map costs a single VGPR.
 // (kernels that read the scene from global memory tend to have deep stacks and an LDS-bound
 // occupancy: they keep the pixel sum in registers instead)
-DEV uint32_t lane_state_dwords(const RenderArgs& a) { return a.lds_scene ? LANE_STATE_DWORDS : 0u; }
+DEV uint32_t lane_state_dwords(const RenderArgs& a) { return (a.lds_scene && RT_TOTAL_IN_LDS) ? LANE_STATE_DWORDS : 0u; }
 DEV uint32_t wave_region_dwords(const RenderArgs& a) {
     return (a.pixel_cache == 1u ? PIXEL_MEMO_DWORDS * 64u : 0u) + lane_state_dwords(a) * 64u +
            stack_dwords(a) + a.tlas_entries * 64u;
@@ -1235,11 +1235,11 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
         memo_hit_load(a, ls, hit);
     } else if (mode == STEP_TRAVERSE) {
         TIC(t0);
-        hit = intersect_scene<LDS, STATS, TLAS>(a, s.ro, s.rd, stack_of<LDS>(ls), node_tests, tri_tests);
+        hit = intersect_scene<LDS, STATS, TLAS>(a, s.ro, s.rd, stack_of<(LDS && RT_TOTAL_IN_LDS)>(ls), node_tests, tri_tests);
         TOC(t0, 0);
         memo_hit_store<STATS>(a, s, ls, hit);
     }
-    return path_end<LDS, LDS>(a, s, ls, mode, hit, n_segments);
+    return path_end<LDS, (LDS && RT_TOTAL_IN_LDS)>(a, s, ls, mode, hit, n_segments);
 }
 
 // wgsl:498 + 154-161
@@ -1310,7 +1310,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     const PixelCoord px = pixel_of(a, tile, threadIdx.x & 63u);
     const bool valid = tile_ok && px.valid;
     PixelState s;
-    pixel_begin<LDS>(a, cam, s, ls, px.x, px.y, px.out_row);
+    pixel_begin<(LDS && RT_TOTAL_IN_LDS)>(a, cam, s, ls, px.x, px.y, px.out_row);
     pixel_cache_begin(a, a, cam, s, ls);
     uint32_t starve = 0;
     bool active = valid && a.params.rays_per_pixel > 0;
@@ -1319,7 +1319,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     while (active) {
         if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, node_tests, tri_tests)) active = false;
     }
-    if (valid) pixel_finish<LDS>(a, s, ls);
+    if (valid) pixel_finish<(LDS && RT_TOTAL_IN_LDS)>(a, s, ls);
     if (a.tile_cost && tile_ok) {  // one store per wave: the tile's rays
         uint32_t sum = n_segments;
         for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
@@ -1350,7 +1350,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
     uint32_t pool_base = 0, pool_left = 0;  // wave-uniform: pixels left in the current tile
     bool exhausted = false;
     PixelState s;
-    pixel_begin<LDS>(a, camera_consts(a), s, ls, 0, 0, 0);
+    pixel_begin<(LDS && RT_TOTAL_IN_LDS)>(a, camera_consts(a), s, ls, 0, 0, 0);
     bool active = false;
     uint32_t n_segments = 0;
     int node_tests = 0, tri_tests = 0;
@@ -1388,13 +1388,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                     if (px.valid) {
                         DIAG(15);
                         const CameraConsts cam = camera_consts(ca);
-                        pixel_begin<LDS>(ca, cam, s, ls, px.x, px.y, px.out_row);
+                        pixel_begin<(LDS && RT_TOTAL_IN_LDS)>(ca, cam, s, ls, px.x, px.y, px.out_row);
                         pixel_cache_begin(a, ca, cam, s, ls);
                         s.meta = (pull_seq & (COST_SLOTS - 1u)) << 16;
                         if (have_samples) {
                             active = true;
                         } else {
-                            pixel_finish<LDS>(ca, s, ls);  // 0 / 0 = NaN, as the shader would store
+                            pixel_finish<(LDS && RT_TOTAL_IN_LDS)>(ca, s, ls);  // 0 / 0 = NaN, as the shader would store
                             if (a.tile_cost) tile_cost_add(a, cost_tbl, s);
                         }
                     }
@@ -1414,7 +1414,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         if (active) {
             if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, node_tests, tri_tests)) {
                 DIAG(16);
-                pixel_finish<LDS>(cold_args(), s, ls);
+                pixel_finish<(LDS && RT_TOTAL_IN_LDS)>(cold_args(), s, ls);
                 if (a.tile_cost) tile_cost_add(a, cost_tbl, s);
                 active = false;
             }
@@ -1441,7 +1441,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
 // ---------------------------------------------------------------------------
 template <bool LDS, bool TLAS>
 __global__ void __launch_bounds__(BLOCK_THREADS) rt_debug_kernel(const RenderArgs a) {
-    uint32_t* stack = stack_of<LDS>(block_prologue<LDS>(a));
+    uint32_t* stack = stack_of<(LDS && RT_TOTAL_IN_LDS)>(block_prologue<LDS>(a));
     const uint32_t tile = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (tile >= a.tiles_x * a.tiles_y) return;
     const PixelCoord px = pixel_of(a, tile, threadIdx.x & 63u);
@@ -1601,7 +1601,7 @@ size_t render_lds_bytes(const RenderArgs& a) {
     size_t stacks = ((size_t)(a.stack_entries ? a.stack_entries : 1u) * (a.stack_wide ? 128u : 64u) + (size_t)a.tlas_entries * 64u) *
                     sizeof(uint32_t) * WAVES_PER_BLOCK;
     size_t cost_tables = 8u * 3u * sizeof(uint32_t) * WAVES_PER_BLOCK;
-    size_t lane_state = a.lds_scene ? (size_t)LANE_STATE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
+    size_t lane_state = (a.lds_scene && RT_TOTAL_IN_LDS) ? (size_t)LANE_STATE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
     size_t cache = a.pixel_cache == 1u ? (size_t)PIXEL_MEMO_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
     // (= 4 x wave_region_dwords + the cost tables, see the LDS map)
     return stacks + cost_tables + lane_state + cache + (a.lds_scene ? a.lay.bytes : 0u);
