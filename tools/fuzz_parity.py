@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Stress version of tests/test_gpu_scenes.py::test_random_scenes: N seeded random scenes, GPU (both kernel
+variants, with and without counters) against the CPU oracle, bit for bit.  usage: fuzz_parity.py [first] [count]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import ray_tracer_2_amd as rt  # noqa: E402
+from oracle import oracle  # noqa: E402
+from test_gpu_scenes import _random_scene  # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+tr = rt.RayTracer(0, 256, 256)
+bad = 0
+for seed in range(first, first + count):
+    arrays = _random_scene(rt, seed)
+    w, h = 64 + 8 * (seed % 9), 40 + 4 * (seed % 7)
+    p = rt.make_params(w, h, 1 + seed % 6, 1 + seed % 4, skybox=seed % 2, frames=0)
+    ref, st = oracle.render(p, arrays)
+    tr.load_scene(arrays)
+    for variant in (0, 1):
+        tr.set_option("kernel_variant", variant)
+        for counters in (True, False):
+            tr.set_counters(counters)
+            tr.reset_timing()
+            tr.render(p)
+            gpu = tr.read_image(w, h)
+            s = tr.stats()
+            ok = np.array_equal(gpu.view(np.uint32), ref.view(np.uint32)) and s.segments == st.segments
+            if counters:
+                ok = ok and (s.node_tests, s.triangle_tests) == (st.node_tests, st.triangle_tests)
+            if not ok:
+                bad += 1
+                print(f"MISMATCH seed {seed} variant {variant} counters {counters}: {int((gpu.view(np.uint32) != ref.view(np.uint32)).sum())} words differ")
+    tr.set_counters(False)
+    if (seed - first) % 50 == 49:
+        print(f"... {seed - first + 1} scenes, {bad} mismatches", flush=True)
+print(f"{count} scenes, {bad} mismatches")
+sys.exit(1 if bad else 0)
