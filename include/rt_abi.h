@@ -257,7 +257,7 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  * primary ray and its hit, 1 = memo in LDS when it fits (default), 2 = memo in global memory;
  * "vote_eighths" (0..8, default 6) and
  * "vote_patience" (default 1) = the intersection vote of the render kernels; "tile_feedback" 0 = do not
- * reorder tiles by an earlier frame's per-tile ray counts, "tile_feedback_period" = frames an order is kept (default 8); "forest" 0 = no forest items (next
+ * reorder tiles by an earlier frame's per-tile ray counts, "tile_feedback_period" = frames an order is kept (default 8); "primary_table" 0 = compute the memoised primary ray per pixel in the render kernel instead of once per (camera, frame size); "forest" 0 = no forest items (next
  * upload); "stack_wide" -1 auto / 0 one-dword BVH stack entries whenever legal / 1 two-dword entries. */
 int rt_set_option(rt_handle* h, const char* name, int value);
 /* Enable/disable the optional per-ray counters (node/triangle tests). */

@@ -23,6 +23,7 @@ hipError_t launch_render(const RenderArgs& a, hipStream_t stream);
 size_t render_lds_bytes(const RenderArgs& a);
 hipError_t launch_tile_order(const uint32_t* cost, uint32_t n_tiles, uint32_t max_cost, uint32_t* order,
                              hipStream_t stream);
+hipError_t launch_primary(const RenderArgs& a, float4* table, hipStream_t stream);
 hipError_t launch_assemble(const float4* gathered, float4* image, uint32_t width, uint32_t height,
                            uint32_t world, unsigned long long pad_texels, hipStream_t stream);
 #if defined(RT_DIAG) || defined(RT_DIAGT)
@@ -64,6 +65,13 @@ struct rt_handle {
     int cost_slot = 0;
     bool history_valid = false;
     uint32_t hist_w = 0, hist_h = 0, hist_rank = 0, hist_world = 0;
+    // primary-ray table (rt_primary_kernel): valid for (camera, width, height)
+    float4* primary = nullptr;
+    size_t primary_texels = 0;
+    bool primary_valid = false;
+    rt_camera_uniform primary_camera{};
+    uint32_t primary_w = 0, primary_h = 0;
+    int use_primary = 1;  // option "primary_table"
     int tile_feedback = 1;
     int tile_feedback_period = 8;  // frames an order is kept before it is refreshed
     bool have_order = false, costs_ready = false;
@@ -258,6 +266,7 @@ void rt_destroy(rt_handle* h) {
     if (h->multi_event) (void)hipEventDestroy(h->multi_event);
     free_dev(h->counters);
     free_dev(h->work_counters);
+    free_dev(h->primary);
     free_dev(h->pixel_cache_mem);
     free_dev(h->tile_cost[0]);
     free_dev(h->tile_cost[1]);
@@ -666,6 +675,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "tile_feedback") {
         h->tile_feedback = value ? 1 : 0;
         h->history_valid = false;
+    } else if (n == "primary_table") {
+        h->use_primary = value ? 1 : 0;
     } else if (n == "tile_feedback_period") {
         if (value < 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "tile_feedback_period must be >= 1");
         h->tile_feedback_period = value;
@@ -790,6 +801,27 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         }
         a.pixel_cache = 2;
         a.pixel_cache_mem = h->pixel_cache_mem;
+    }
+    // Primary-ray table for the memo: recomputed when the camera or the frame size changed
+    a.primary = nullptr;
+    if (h->use_primary && a.pixel_cache != 0 && params->debug_flag == 0 && params->rays_per_pixel > 0) {
+        const size_t texels = (size_t)params->width * params->height;
+        if (h->primary_texels < texels) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            free_dev(h->primary);
+            HIP_TRY(h, hipMalloc((void**)&h->primary, texels * sizeof(float4)));
+            h->primary_texels = texels;
+            h->primary_valid = false;
+        }
+        if (!h->primary_valid || h->primary_w != params->width || h->primary_h != params->height ||
+            memcmp(&h->primary_camera, &h->camera, sizeof(rt_camera_uniform)) != 0) {
+            HIP_TRY(h, launch_primary(a, h->primary, h->stream));
+            h->primary_valid = true;
+            h->primary_w = params->width;
+            h->primary_h = params->height;
+            h->primary_camera = h->camera;
+        }
+        a.primary = h->primary;
     }
     // a fresh tile counter per launch: a ring of 64, zeroed in one go each time it wraps (launches on
     // one stream are ordered, so every earlier user of the ring is done by then)

@@ -990,16 +990,16 @@ DEV void with_memo(const RenderArgs& a, uint32_t* ls, F&& f) {
 
 // Called when a lane takes a new pixel: computes the pixel's constant primary ray when the
 // camera has no jitter and no -0 is involved (see path_step), else marks the memo empty.
+// the memoised primary ray of pixel (x, y): direction, and whether the ray is constant at all
 template <class A>
-DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts& c, const PixelState& s, uint32_t* ls) {
-    if (!a.pixel_cache) return;
-    const f3 focus = focus_point_of(ca, c, s.x, frame_row_of(ca, s.out_row));
-    auto not_neg_zero = [](float x) { return __float_as_uint(x) != 0x80000000u; };
+DEV f3 memo_ray_of(const A& ca, const CameraConsts& c, uint32_t x, uint32_t y, bool& constant_ray) {
+    const f3 focus = focus_point_of(ca, c, x, y);
+    auto not_neg_zero = [](float v) { return __float_as_uint(v) != 0x80000000u; };
     auto finite3 = [](f3 v) { return rtm::abs_(v.x) < INF && rtm::abs_(v.y) < INF && rtm::abs_(v.z) < INF; };
-    const bool constant_ray = __float_as_uint(ca.camera.defocus_strength) == 0u &&
-                              __float_as_uint(ca.camera.diverge_strength) == 0u && finite3(c.right) && finite3(c.up) &&
-                              not_neg_zero(c.origin.x) && not_neg_zero(c.origin.y) && not_neg_zero(c.origin.z) &&
-                              not_neg_zero(focus.x) && not_neg_zero(focus.y) && not_neg_zero(focus.z);
+    constant_ray = __float_as_uint(ca.camera.defocus_strength) == 0u &&
+                   __float_as_uint(ca.camera.diverge_strength) == 0u && finite3(c.right) && finite3(c.up) &&
+                   not_neg_zero(c.origin.x) && not_neg_zero(c.origin.y) && not_neg_zero(c.origin.z) &&
+                   not_neg_zero(focus.x) && not_neg_zero(focus.y) && not_neg_zero(focus.z);
     f3 rd{0, 0, 0};
     if (constant_ray) {
         // x + (+-0) + (+-0) is x for x != 0 and +0 for x = +0: the jitter signs cannot matter
@@ -1009,6 +1009,25 @@ DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts&
         const f3 jfp = (focus + c.right * 0.0f) + c.up * 0.0f;
         rd = normalize3(jfp - ro);
         rd = normalize3(rd);  // wgsl:400
+    }
+    return rd;
+}
+
+template <class A>
+DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts& c, const PixelState& s, uint32_t* ls) {
+    if (!a.pixel_cache) return;
+    bool constant_ray;
+    f3 rd;
+    const uint32_t y = frame_row_of(ca, s.out_row);
+    if (a.primary) {
+        // camera and frame size have not changed since rt_primary_kernel filled the table: the same
+        // values, computed there with every lane busy instead of here with a handful
+        const __attribute__((address_space(1))) float* v =
+            (const __attribute__((address_space(1))) float*)a.primary + ((size_t)y * ca.params.width + s.x) * 4u;
+        rd = f3{v[0], v[1], v[2]};
+        constant_ray = v[3] != 0.0f;
+    } else {
+        rd = memo_ray_of(ca, c, s.x, y, constant_ray);
     }
     with_memo(a, ls, [&](auto pc) {
         pc[0] = __float_as_uint(rd.x); pc[64] = __float_as_uint(rd.y); pc[128] = __float_as_uint(rd.z);
@@ -1523,6 +1542,18 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rt_debug_kernel(const RenderArg
 // Scatter gathered strips (rank-major, each rank padded to `pad_texels`) into
 // the full frame: strip s of the frame is local strip s / world of rank
 // s % world.
+// Primary-ray table: (direction, constant-ray flag) of every pixel of the frame, for the memo of
+// the render kernels.  Depends on the camera and the frame size only, so progressive accumulation
+// computes it once.
+__global__ void __launch_bounds__(256) rt_primary_kernel(const RenderArgs a, float4* __restrict__ table) {
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= a.params.width || y >= a.params.height) return;
+    const CameraConsts c = camera_consts(a);
+    bool constant_ray;
+    const f3 rd = memo_ray_of(a, c, x, y, constant_ray);
+    table[(size_t)y * a.params.width + x] = make_float4(rd.x, rd.y, rd.z, constant_ray ? 1.0f : 0.0f);
+}
+
 __global__ void rt_assemble_kernel(const float4* __restrict__ gathered, float4* __restrict__ image,
                                    uint32_t width, uint32_t height, uint32_t world,
                                    unsigned long long pad_texels) {
@@ -1645,6 +1676,12 @@ hipError_t launch_render(const RenderArgs& a, hipStream_t stream) {
         if (tlas) launch_variant<false, true>(a, ntiles, lds, stream);
         else launch_variant<false, false>(a, ntiles, lds, stream);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_primary(const RenderArgs& a, float4* table, hipStream_t stream) {
+    if (a.params.width == 0 || a.params.height == 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_primary_kernel, dim3((a.params.width + 63u) / 64u, (a.params.height + 3u) / 4u), dim3(256), 0, stream, a, table);
     return hipGetLastError();
 }
 
