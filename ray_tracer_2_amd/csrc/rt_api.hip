@@ -23,7 +23,7 @@ hipError_t launch_render(const RenderArgs& a, hipStream_t stream);
 size_t render_lds_bytes(const RenderArgs& a);
 hipError_t launch_tile_order(const uint32_t* cost, uint32_t n_tiles, uint32_t max_cost, uint32_t* order,
                              hipStream_t stream);
-hipError_t launch_primary(const RenderArgs& a, float4* table, hipStream_t stream);
+hipError_t launch_primary(const RenderArgs& a, float* table, hipStream_t stream);
 hipError_t launch_assemble(const float4* gathered, float4* image, uint32_t width, uint32_t height,
                            uint32_t world, unsigned long long pad_texels, hipStream_t stream);
 #if defined(RT_DIAG) || defined(RT_DIAGT)
@@ -66,7 +66,7 @@ struct rt_handle {
     bool history_valid = false;
     uint32_t hist_w = 0, hist_h = 0, hist_rank = 0, hist_world = 0;
     // primary-ray table (rt_primary_kernel): valid for (camera, width, height)
-    float4* primary = nullptr;
+    float* primary = nullptr;
     size_t primary_texels = 0;
     bool primary_valid = false;
     rt_camera_uniform primary_camera{};
@@ -809,7 +809,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         if (h->primary_texels < texels) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             free_dev(h->primary);
-            HIP_TRY(h, hipMalloc((void**)&h->primary, texels * sizeof(float4)));
+            HIP_TRY(h, hipMalloc((void**)&h->primary, texels * 3 * sizeof(float)));
             h->primary_texels = texels;
             h->primary_valid = false;
         }

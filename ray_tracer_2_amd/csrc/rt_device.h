@@ -138,7 +138,7 @@ struct RenderArgs {
     uint32_t pixel_cache;    // per-lane primary-ray memo (PIXEL_MEMO_DWORDS per lane): 0 off, 1 in LDS,
                              // 2 in `pixel_cache_mem` (persistent kernel only, when LDS has no room)
     uint32_t* pixel_cache_mem;
-    const float4* primary;   // primary-ray table of the frame (rt_primary_kernel), or null: compute per pixel
+    const float* primary;    // primary-ray table of the frame (rt_primary_kernel: 3 floats per pixel), or null: compute per pixel
     float memo_ro[3];        // (origin + right * 0) + up * 0: the memoised primary rays' common origin
     uint32_t vote_eighths;   // intersection vote: run when wanting lanes * 8 >= lanes * vote_eighths
     uint32_t vote_patience;  // ... or when somebody has waited this many iterations

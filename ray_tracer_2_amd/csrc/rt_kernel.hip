@@ -1022,10 +1022,12 @@ DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts&
     if (a.primary) {
         // camera and frame size have not changed since rt_primary_kernel filled the table: the same
         // values, computed there with every lane busy instead of here with a handful
+        // (12 bytes per pixel; a NaN x marks "not constant": a constant ray that is NaN itself then
+        // merely takes the per-sample path, which computes the same NaN)
         const __attribute__((address_space(1))) float* v =
-            (const __attribute__((address_space(1))) float*)a.primary + ((size_t)y * ca.params.width + s.x) * 4u;
+            (const __attribute__((address_space(1))) float*)a.primary + ((size_t)y * ca.params.width + s.x) * 3u;
         rd = f3{v[0], v[1], v[2]};
-        constant_ray = v[3] != 0.0f;
+        constant_ray = rd.x == rd.x;
     } else {
         rd = memo_ray_of(ca, c, s.x, y, constant_ray);
     }
@@ -1545,13 +1547,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rt_debug_kernel(const RenderArg
 // Primary-ray table: (direction, constant-ray flag) of every pixel of the frame, for the memo of
 // the render kernels.  Depends on the camera and the frame size only, so progressive accumulation
 // computes it once.
-__global__ void __launch_bounds__(256) rt_primary_kernel(const RenderArgs a, float4* __restrict__ table) {
+__global__ void __launch_bounds__(256) rt_primary_kernel(const RenderArgs a, float* __restrict__ table) {
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (x >= a.params.width || y >= a.params.height) return;
     const CameraConsts c = camera_consts(a);
     bool constant_ray;
     const f3 rd = memo_ray_of(a, c, x, y, constant_ray);
-    table[(size_t)y * a.params.width + x] = make_float4(rd.x, rd.y, rd.z, constant_ray ? 1.0f : 0.0f);
+    float* t = table + ((size_t)y * a.params.width + x) * 3u;
+    t[0] = constant_ray ? rd.x : __uint_as_float(0x7fc00000u);
+    t[1] = rd.y;
+    t[2] = rd.z;
 }
 
 __global__ void rt_assemble_kernel(const float4* __restrict__ gathered, float4* __restrict__ image,
@@ -1679,7 +1684,7 @@ hipError_t launch_render(const RenderArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_primary(const RenderArgs& a, float4* table, hipStream_t stream) {
+hipError_t launch_primary(const RenderArgs& a, float* table, hipStream_t stream) {
     if (a.params.width == 0 || a.params.height == 0) return hipSuccess;
     hipLaunchKernelGGL(rt_primary_kernel, dim3((a.params.width + 63u) / 64u, (a.params.height + 3u) / 4u), dim3(256), 0, stream, a, table);
     return hipGetLastError();
