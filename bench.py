@@ -224,7 +224,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rt_render_persistent_kernel<true, false, false>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "path is FP32-VALU-issue-bound (SURVEY 8d, DESIGN.md): compulsory HBM bytes are ~66 MB/frame"},
+                         "note": "path is FP32-VALU-issue-bound (SURVEY 8d, DESIGN.md): compulsory HBM bytes are ~66 MB/frame; "
+                                 "measured traffic also holds the 25 MB/frame primary-ray table (12 B/pixel, read once: it "
+                                 "replaces per-pixel ray set-up at 9 % lane utilisation) and 16-B texel stores that touch a "
+                                 "64-B sector more than once (pixels finish lane by lane)"},
         }
         if valu is not None:
             out["roofline_valu"] = valu

@@ -805,7 +805,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     // Primary-ray table for the memo: recomputed when the camera or the frame size changed
     a.primary = nullptr;
     if (h->use_primary && a.pixel_cache != 0 && params->debug_flag == 0 && params->rays_per_pixel > 0) {
-        const size_t texels = (size_t)params->width * params->height;
+        const size_t texels = (size_t)((params->width + 7) / 8) * ((params->height + 7) / 8) * 64;  // whole 8x8 tiles
         if (h->primary_texels < texels) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             free_dev(h->primary);

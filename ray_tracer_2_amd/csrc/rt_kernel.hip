@@ -990,6 +990,11 @@ DEV void with_memo(const RenderArgs& a, uint32_t* ls, F&& f) {
 
 // Called when a lane takes a new pixel: computes the pixel's constant primary ray when the
 // camera has no jitter and no -0 is involved (see path_step), else marks the memo empty.
+DEV size_t primary_index(uint32_t width, uint32_t x, uint32_t y) {
+    const uint32_t tiles_x = (width + 7u) >> 3;
+    return ((size_t)(y >> 3) * tiles_x + (x >> 3)) * 64u + (((y & 7u) << 3) | (x & 7u));
+}
+
 // the memoised primary ray of pixel (x, y): direction, and whether the ray is constant at all
 template <class A>
 DEV f3 memo_ray_of(const A& ca, const CameraConsts& c, uint32_t x, uint32_t y, bool& constant_ray) {
@@ -1024,8 +1029,10 @@ DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts&
         // values, computed there with every lane busy instead of here with a handful
         // (12 bytes per pixel; a NaN x marks "not constant": a constant ray that is NaN itself then
         // merely takes the per-sample path, which computes the same NaN)
+        // table order = the order in which lanes take pixels (8x8 tile by tile, row-major inside): the
+        // lanes refilled together read neighbouring entries
         const __attribute__((address_space(1))) float* v =
-            (const __attribute__((address_space(1))) float*)a.primary + ((size_t)y * ca.params.width + s.x) * 3u;
+            (const __attribute__((address_space(1))) float*)a.primary + primary_index(ca.params.width, s.x, y) * 3u;
         rd = f3{v[0], v[1], v[2]};
         constant_ray = rd.x == rd.x;
     } else {
@@ -1553,7 +1560,7 @@ __global__ void __launch_bounds__(256) rt_primary_kernel(const RenderArgs a, flo
     const CameraConsts c = camera_consts(a);
     bool constant_ray;
     const f3 rd = memo_ray_of(a, c, x, y, constant_ray);
-    float* t = table + ((size_t)y * a.params.width + x) * 3u;
+    float* t = table + primary_index(a.params.width, x, y) * 3u;
     t[0] = constant_ray ? rd.x : __uint_as_float(0x7fc00000u);
     t[1] = rd.y;
     t[2] = rd.z;
