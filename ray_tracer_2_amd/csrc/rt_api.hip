@@ -742,6 +742,13 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         volatile float t = h->camera.cam_to_world[3][k] + rz;
         a.memo_ro[k] = t + uz;
     }
+    {
+        // (i32 arithmetic wraps in the shader; frames = -1 gives +inf there too)
+        volatile float w = 1.0f / (float)(int32_t)((uint32_t)params->frames + 1u);
+        volatile float r = 1.0f - w;
+        a.blend_weight = w;
+        a.blend_rest = r;
+    }
     a.blob = h->blob;
     a.lay = h->lay;
     a.lds_scene = (h->lds_scene && !h->force_global) ? 1u : 0u;

@@ -832,8 +832,9 @@ DEV void store_texel(const A& a, uint32_t x, uint32_t out_row, f4 cur) {
     float4* texel = a.image + (size_t)out_row * a.params.width + x;
     if (a.params.frames >= 1) {
         float4 prev = *texel;
-        float weight = 1.0f / (float)(a.params.frames + 1);
-        float om = 1.0f - weight;
+        // wgsl:157: weight = 1 / f32(frames + 1), evaluated once per launch by the host with the
+        // same two operations (RenderArgs::blend_weight, ::blend_rest)
+        const float weight = a.blend_weight, om = a.blend_rest;
         *texel = make_float4(prev.x * om + cur.x * weight, prev.y * om + cur.y * weight,
                              prev.z * om + cur.z * weight, prev.w * om + cur.w * weight);
     } else {
