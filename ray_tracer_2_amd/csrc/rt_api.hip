@@ -749,6 +749,10 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         a.blend_weight = w;
         a.blend_rest = r;
     }
+    {
+        const int32_t n = params->rays_per_pixel;
+        a.spp_reciprocal = (n > 0 && (n & (n - 1)) == 0) ? 1.0f / (float)n : 0.0f;
+    }
     a.blob = h->blob;
     a.lay = h->lay;
     a.lds_scene = (h->lds_scene && !h->force_global) ? 1u : 0u;

@@ -1278,7 +1278,11 @@ DEV void pixel_finish(const A& a, const PixelState& s, const uint32_t* ls) {
     f4 total = s.total;
     if constexpr (LDS)
         total = f4{__uint_as_float(ls[0]), __uint_as_float(ls[64]), __uint_as_float(ls[128]), __uint_as_float(ls[192])};
-    store_texel(a, s.x, s.out_row, f4{total.x / n, total.y / n, total.z / n, total.w / n});
+    // wgsl:498: total / f32(rays_per_pixel).  When the count is a power of two its reciprocal is
+    // exact, and x * (1/n) and x / n are the same real number rounded once: the same float.
+    const float r = a.spp_reciprocal;  // 0: not a power of two
+    if (r != 0.0f) store_texel(a, s.x, s.out_row, f4{total.x * r, total.y * r, total.z * r, total.w * r});
+    else store_texel(a, s.x, s.out_row, f4{total.x / n, total.y / n, total.z / n, total.w / n});
 }
 
 // Tile-cost feedback (rays per 8x8 tile, read by the next frame's scheduler).  A persistent
