@@ -180,6 +180,7 @@ typedef struct rt_stats {
     uint64_t triangle_tests; /* as wgsl:307 counts them */
     float kernel_ms;         /* sum of the hipEvent times of `launches` render launches */
     uint32_t launches;       /* render launches since the last rt_reset_timing */
+    uint32_t frames;         /* frames those launches rendered (rt_render_frames: several per launch) */
 } rt_stats;
 
 /* ≙ RayTracer::new + create_gpu_resources (ray_tracer.rs:49,316): picks the
@@ -209,10 +210,23 @@ int rt_set_camera(rt_handle* h, const rt_camera_uniform* camera);
  * params->frames >= 1 (wgsl:154-161).  Asynchronous on the handle's stream. */
 int rt_render(rt_handle* h, const rt_params* params);
 
+/* n_frames consecutive frames of RayTracer::render with Params.frames advancing by one per frame, as
+ * App::update does while accumulating (app.rs:44-53, 160-162): the image afterwards is bit-identical to
+ * n_frames calls of rt_render with frames, frames + 1, ...  The only dependency between frames is the
+ * per-texel blend (wgsl:154-161), so the frames of a batch (option "batch_frames", default 16, at most
+ * 32) are sampled by ONE persistent launch over (frame, tile) work items -- the waves never drain
+ * between frames -- into scratch images, and a dense second kernel blends them in frame order with
+ * the shader's two operations.  Intermediate frames of a batch are not observable. */
+int rt_render_frames(rt_handle* h, const rt_params* params, uint32_t n_frames);
+
 /* Multi-GPU tile split: renders only the 8-row strips s with
  * s % world == rank into the compact local image (strip-major).  Seeds use
  * the full-frame pixel index, so the stitched image equals rt_render's. */
 int rt_render_strips(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world);
+
+/* rt_render_frames for one rank's strips. */
+int rt_render_strips_frames(rt_handle* h, const rt_params* params, uint32_t n_frames, uint32_t rank,
+                            uint32_t world);
 
 /* Number of texels rt_render_strips(rank, world) writes. */
 uint64_t rt_strip_texels(uint32_t width, uint32_t height, uint32_t rank, uint32_t world);
@@ -229,6 +243,16 @@ int rt_assemble_strips(rt_handle* h, const void* gathered_device, uint32_t width
  * full frame (width*height RGBA32F) is copied there (blocking).  Every handle keeps
  * its own strip accumulation across frames.  The frame is bit-identical to rt_render's. */
 int rt_render_multi(rt_handle** per_gpu, int n_gpus, const rt_params* params, float* rgba32f_out);
+/* The same for n_frames consecutive frames (rt_render_strips_frames on every GPU), ONE gather at the
+ * end.  Transport of the gather: RCCL (grouped ncclSend/ncclRecv, every peer on its own xGMI link to the
+ * root; librccl is loaded on first use) between distinct devices, device-to-device copies (peer access
+ * enabled where the devices allow it) between handles that share a device or when option "multi_rccl"
+ * of per_gpu[0] is 0.  Non-blocking when rgba32f_out is NULL: a later call may follow at once (each
+ * rank's next render waits for the root's copy of its previous strips). */
+int rt_render_multi_frames(rt_handle** per_gpu, int n_gpus, const rt_params* params, uint32_t n_frames,
+                           float* rgba32f_out);
+/* Blocking read of the frame the last rt_render_multi* call assembled on the root. */
+int rt_read_multi_frame(rt_handle* root, float* rgba32f_out, size_t bytes);
 
 /* ≙ copy_texture_to_buffer in save_render_to_file (app.rs:341-407): blocking
  * copy of width*height RGBA32F texels (row 0 = bottom of the view). */
@@ -257,7 +281,7 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  * primary ray and its hit, 1 = memo in LDS when it fits (default), 2 = memo in global memory;
  * "vote_eighths" (0..8, default 6) and
  * "vote_patience" (default 1) = the intersection vote of the render kernels; "tile_feedback" 0 = do not
- * reorder tiles by an earlier frame's per-tile ray counts, "tile_feedback_period" = frames an order is kept (default 8); "primary_table" 0 = compute the memoised primary ray per pixel in the render kernel instead of once per (camera, frame size); "forest" 0 = no forest items (next
+ * reorder tiles by an earlier frame's per-tile ray counts, "tile_feedback_period" = frames an order is kept (default 8); "batch_frames" = frames per launch of rt_render_frames (1..32, default 16); "multi_rccl" = gather transport of rt_render_multi (see there); "primary_table" 0 = compute the memoised primary ray per pixel in the render kernel instead of once per (camera, frame size); "forest" 0 = no forest items (next
  * upload); "stack_wide" -1 auto / 0 one-dword BVH stack entries whenever legal / 1 two-dword entries. */
 int rt_set_option(rt_handle* h, const char* name, int value);
 /* Enable/disable the optional per-ray counters (node/triangle tests). */

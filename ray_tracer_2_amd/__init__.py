@@ -7,5 +7,5 @@ package is the thin Python face used by tests and bench.py.
 from ._abi import (CameraUniform, Material, MeshUniform, Node, PackedTriangle, Params,  # noqa: F401
                    SceneUniform, Sphere, make_params)
 from .lib import LIB_PATH, RtError, load  # noqa: F401
-from .ray_tracer import RayTracer, render_multi  # noqa: F401
+from .ray_tracer import RayTracer, read_multi_frame, render_multi  # noqa: F401
 from .scene import Scene, SceneArrays, material, transform  # noqa: F401

@@ -42,22 +42,38 @@ def hipcc_path():
             return p
 
 
-def build_product(force=False, extra_flags=()):
+def build_product(force=False, extra_flags=(), out=None, jobs=4):
+    """Compile every product source to an object (in parallel, only the ones whose inputs changed)
+    and link librt2_mi355x.so.  `extra_flags` / `out` build an instrumented variant beside it
+    (tools/diag.py)."""
+    import concurrent.futures
+    import hashlib
+    out = out or PRODUCT_SO
     srcs = [os.path.join(CSRC, s) for s in PRODUCT_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in PRODUCT_HEADERS] + [os.path.abspath(__file__)]   # (flags live in this file)
-    if not force and not _newer(PRODUCT_SO, deps):
-        return PRODUCT_SO
+    hdrs = [os.path.join(CSRC, h) for h in PRODUCT_HEADERS] + [os.path.abspath(__file__)]   # (flags live in this file)
     # -ffp-contract=off: the canonical arithmetic is unfused (every fused
     # operation is an explicit fma in rt_transc.h); division and sqrt stay
     # correctly rounded (hipcc default, no fast-math).
     # -fno-slp-vectorize: the SLP vectoriser's automatic v_pk_*_f32 packing pays for itself in
-    # v_mov shuffles here (measured: 2.22 -> 2.09 ms on config 2 without it); the packed forms
-    # that do pay (the slab tests) are written out with 2-vectors in rt_kernel.hip.
-    cmd = [hipcc_path(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
-           "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
-           "-I", os.path.join(ROOT, "include"), *extra_flags, *srcs, "-lz", "-o", PRODUCT_SO]
-    _run(cmd)
-    return PRODUCT_SO
+    # v_mov shuffles here (measured: 2.22 -> 2.09 ms on config 2 without it).
+    flags = ["-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+             "-fno-slp-vectorize", "-fPIC", "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"),
+             *extra_flags]
+    tag = hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:8] if extra_flags else "product"
+    objdir = os.path.join(ROOT, "build", tag)
+    os.makedirs(objdir, exist_ok=True)
+    objs, todo = [], []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            todo.append([hipcc_path(), *flags, "-c", s, "-o", o])
+    if todo:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+            list(ex.map(_run, todo))
+    if todo or _newer(out, objs):
+        _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-ldl", "-o", out])
+    return out
 
 
 def build_oracle(force=False):

@@ -7,11 +7,15 @@
 // aborts across the boundary).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is loaded on first multi-device use
+
 #include <algorithm>
 #include <cfloat>
 #include <cstring>
 #include <functional>
 #include <new>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -24,6 +28,7 @@ size_t render_lds_bytes(const RenderArgs& a);
 hipError_t launch_tile_order(const uint32_t* cost, uint32_t n_tiles, uint32_t max_cost, uint32_t* order,
                              hipStream_t stream);
 hipError_t launch_primary(const RenderArgs& a, float* table, hipStream_t stream);
+hipError_t launch_blend_frames(const BlendArgs& b, hipStream_t stream);
 hipError_t launch_assemble(const float4* gathered, float4* image, uint32_t width, uint32_t height,
                            uint32_t world, unsigned long long pad_texels, hipStream_t stream);
 #if defined(RT_DIAG) || defined(RT_DIAGT)
@@ -43,6 +48,22 @@ struct rt_handle {
     // one (start, stop) event pair per launch since the last rt_reset_timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
+    // launches whose event pairs were harvested when the pool wrapped (rt_get_stats adds the live ones)
+    double ev_ms_harvested = 0.0;
+    unsigned long long launches_total = 0, frames_total = 0;  // since rt_reset_timing
+    // frame batches (rt_render_frames): scratch images of the frames in flight
+    float4* batch_scratch = nullptr;
+    size_t batch_scratch_texels = 0;
+    int batch_frames_opt = 16;  // option "batch_frames": frames per launch of rt_render_frames (1..RT_MAX_BATCH_FRAMES)
+    // rt_render_multi: what the root's stream has to finish before this handle's image may be overwritten
+    hipEvent_t multi_copied = nullptr;  // (owned by the root handle, below)
+    bool multi_copy_pending = false;
+    // root side of rt_render_multi
+    std::vector<hipEvent_t> multi_copied_events;
+    std::vector<void*> multi_comms;       // ncclComm_t per rank
+    std::vector<int> multi_comm_devices;  // the device list the communicators were made for
+    std::set<int> multi_peers_enabled;
+    int multi_rccl = 1;  // option "multi_rccl"
     float4* own_image = nullptr;  // allocated by rt_create; `image` may be rebound
     float4* multi_gathered = nullptr;  // rt_render_multi root: [world][pad_texels]
     float4* multi_frame = nullptr;     // rt_render_multi root: assembled full frame
@@ -190,6 +211,60 @@ int mesh_bvh_height(const rt_node* nodes, uint32_t n_nodes, uint32_t node_offset
 
 }  // namespace
 
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) {
+            why = std::string("cannot load librccl: ") + dlerror();
+            return false;
+        }
+        auto sym = [&](const char* n) { void* f = dlsym(lib, n); if (!f) why = std::string("librccl lacks ") + n; return f; };
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
+            dlclose(lib);
+            lib = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+RcclApi g_rccl;
+
+#define NCCL_TRY(h, expr)                                                                          \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess)                                                                     \
+            return fail(h, RT_ERR_DEVICE, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+void multi_drop_comms(rt_handle* root) {
+    if (g_rccl.lib)
+        for (void* c : root->multi_comms) (void)g_rccl.CommDestroy((ncclComm_t)c);
+    root->multi_comms.clear();
+    root->multi_comm_devices.clear();
+}
+}  // namespace
+
 extern "C" {
 
 const char* rt_version(void) { return "ray_tracer_2_amd 0.1 (gfx950)"; }
@@ -263,7 +338,11 @@ void rt_destroy(rt_handle* h) {
     free_dev(h->own_image);
     free_dev(h->multi_gathered);
     free_dev(h->multi_frame);
+    free_dev(h->batch_scratch);
     if (h->multi_event) (void)hipEventDestroy(h->multi_event);
+    for (hipEvent_t e : h->multi_copied_events) (void)hipEventDestroy(e);
+    if (g_rccl.lib)
+        for (void* c : h->multi_comms) (void)g_rccl.CommDestroy((ncclComm_t)c);
     free_dev(h->counters);
     free_dev(h->work_counters);
     free_dev(h->primary);
@@ -705,6 +784,12 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         h->cull_roots = value;
     } else if (n == "lds_scene") {
         h->force_global = value ? 0 : 1;
+    } else if (n == "multi_rccl") {
+        if (value < 0 || value > 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "multi_rccl must be 0 (peer copies), 1 (RCCL between distinct devices) or 2 (RCCL always)");
+        h->multi_rccl = value;
+    } else if (n == "batch_frames") {
+        if (value < 1 || value > (int)RT_MAX_BATCH_FRAMES) return fail(h, RT_ERR_INVALID_ARGUMENT, "batch_frames must be 1..32");
+        h->batch_frames_opt = value;
     } else {
         return fail(h, RT_ERR_INVALID_ARGUMENT, "unknown option " + n);
     }
@@ -724,7 +809,10 @@ uint64_t rt_strip_texels(uint32_t width, uint32_t height, uint32_t rank, uint32_
     return (uint64_t)local * 8u * width;
 }
 
-static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world) {
+// One launch of the hot path: a single frame (n_batch == 0: wgsl `main`, blending in place), or a batch
+// of n_batch >= 2 consecutive frames (Params.frames advancing by one each, app.rs:44-53) sampled in one
+// persistent launch over (frame, tile) work items and blended in frame order by a dense second kernel.
+static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world, uint32_t n_batch = 0) {
     if (!h || !params) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
     if (!h->have_scene) return fail(h, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
     if (world == 0 || rank >= world) return fail(h, RT_ERR_INVALID_ARGUMENT, "bad rank/world");
@@ -734,9 +822,28 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     if (need_texels > h->image_texels)
         return fail(h, RT_ERR_CAPACITY, "image larger than the bound image buffer");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->multi_copy_pending) {
+        // rt_render_multi: the root may still be copying this handle's previous frame
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->multi_copied, 0));
+        h->multi_copy_pending = false;
+    }
     RenderArgs a{};
     a.params = *params;
     a.camera = h->camera;
+    if (n_batch) {
+        if (n_batch > RT_MAX_BATCH_FRAMES) return fail(h, RT_ERR_INVALID_ARGUMENT, "batch too large");
+        if (h->batch_scratch_texels < need_texels * n_batch) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            free_dev(h->batch_scratch);
+            h->batch_scratch_texels = 0;
+            HIP_TRY(h, hipMalloc((void**)&h->batch_scratch, need_texels * n_batch * sizeof(float4)));
+            h->batch_scratch_texels = need_texels * n_batch;
+            // (the padding rows of a ragged last strip are never rendered: they blend as zeros)
+            HIP_TRY(h, hipMemsetAsync(h->batch_scratch, 0, need_texels * n_batch * sizeof(float4), h->stream));
+        }
+        a.batch_frames = n_batch;
+        a.batch_stride = need_texels;
+    }
     for (int k = 0; k < 3; ++k) {  // see pixel_cache_begin: the same IEEE operations, unfused
         volatile float rz = h->camera.cam_to_world[0][k] * 0.0f, uz = h->camera.cam_to_world[1][k] * 0.0f;
         volatile float t = h->camera.cam_to_world[3][k] + rz;
@@ -762,7 +869,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     // the per-lane primary-ray cache is used when it still leaves room for 4 workgroups per CU
     a.textures = h->textures;
     a.srgb_lut = h->srgb_lut;
-    a.image = h->image;
+    a.image = n_batch ? h->batch_scratch : h->image;
     a.counters = h->counters;
     a.n_meshes = h->n_meshes;
     a.n_spheres = h->n_spheres;
@@ -782,6 +889,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     const uint32_t resident_waves = h->persistent_blocks * WAVES_PER_BLOCK;
     a.kernel_variant = h->kernel_variant >= 0 ? (uint32_t)h->kernel_variant
                                               : ((uint64_t)a.tiles_x * a.tiles_y * 4 <= (uint64_t)resident_waves * 5 ? 1u : 0u);
+    if (n_batch) a.kernel_variant = 0;  // (frame, tile) work items are the persistent kernel's
     // (all fields that size the LDS are set by now)
     a.vote_eighths = (uint32_t)h->vote_eighths;
     a.vote_patience = (uint32_t)h->vote_patience;
@@ -862,14 +970,15 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             h->order_age = 0;
             h->costs_ready = false;
         }
+        const uint32_t frames_now = n_batch ? n_batch : 1u;
         if (h->have_order) a.tile_order = h->tile_order;
-        if (!h->have_order || h->order_age + 1u >= (uint32_t)h->tile_feedback_period) {
+        if (!h->have_order || h->order_age + frames_now >= (uint32_t)h->tile_feedback_period) {
             h->cost_slot ^= 1;
             a.tile_cost = h->tile_cost[h->cost_slot];
             HIP_TRY(h, hipMemsetAsync(a.tile_cost, 0, (size_t)n_tiles * sizeof(uint32_t), h->stream));
             h->costs_ready = true;
         }
-        h->order_age += 1;
+        h->order_age += frames_now;
         h->history_valid = true;
         h->hist_w = params->width;
         h->hist_h = params->height;
@@ -878,7 +987,14 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     }
     if (h->ev_used == h->ev_pool.size()) {
         if (h->ev_pool.size() >= 4096) {
-            h->ev_used = 0;  // wrap: only the most recent launches are kept
+            // the pool is full: add the recorded times to the running total, then reuse the events
+            HIP_TRY(h, hipEventSynchronize(h->ev_pool[h->ev_used - 1].second));
+            for (size_t i = 0; i < h->ev_used; ++i) {
+                float ms = 0.0f;
+                HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+                h->ev_ms_harvested += ms;
+            }
+            h->ev_used = 0;
         } else {
             hipEvent_t s0 = nullptr, s1 = nullptr;
             HIP_TRY(h, hipEventCreate(&s0));
@@ -889,7 +1005,25 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     auto& ev = h->ev_pool[h->ev_used++];
     HIP_TRY(h, hipEventRecord(ev.first, h->stream));
     HIP_TRY(h, launch_render(a, h->stream));
+    if (n_batch) {
+        BlendArgs b{};
+        b.image = h->image;
+        b.scratch = h->batch_scratch;
+        b.texels = need_texels;
+        b.stride = need_texels;
+        b.n = n_batch;
+        b.frames0 = params->frames;
+        for (uint32_t k = 0; k < n_batch; ++k) {  // wgsl:157-158 per frame: the same two IEEE operations
+            volatile float w = 1.0f / (float)(int32_t)((uint32_t)params->frames + k + 1u);
+            volatile float r = 1.0f - w;
+            b.weight[k] = w;
+            b.rest[k] = r;
+        }
+        HIP_TRY(h, launch_blend_frames(b, h->stream));
+    }
     HIP_TRY(h, hipEventRecord(ev.second, h->stream));
+    h->launches_total += 1;
+    h->frames_total += n_batch ? n_batch : 1u;
     if (params->debug_flag == 0 && params->rays_per_pixel > 0) {
         // pixels this call renders (strips are clipped to the image height)
         unsigned long long rows = 0;
@@ -897,15 +1031,41 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             uint32_t y0 = st * 8, y1 = y0 + 8 < params->height ? y0 + 8 : params->height;
             rows += y1 - y0;
         }
-        h->paths_total += rows * params->width * (unsigned long long)params->rays_per_pixel;
+        h->paths_total += rows * params->width * (unsigned long long)params->rays_per_pixel * (n_batch ? n_batch : 1u);
+    }
+    return RT_OK;
+}
+
+// n consecutive frames; batches of "batch_frames" frames per launch.  Debug views, single frames and
+// frames without samples take the one-frame path (nothing to overlap).
+static int render_frames_impl(rt_handle* h, const rt_params* params, uint32_t n_frames, uint32_t rank, uint32_t world) {
+    if (!h || !params) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    rt_params p = *params;
+    uint32_t done = 0;
+    while (done < n_frames) {
+        uint32_t n = n_frames - done;
+        if (n > (uint32_t)h->batch_frames_opt) n = (uint32_t)h->batch_frames_opt;
+        if (params->debug_flag != 0 || params->rays_per_pixel <= 0) n = 1;
+        p.frames = (int32_t)((uint32_t)params->frames + done);
+        const int rc = render_impl(h, &p, rank, world, n >= 2 ? n : 0u);
+        if (rc != RT_OK) return rc;
+        done += n;
     }
     return RT_OK;
 }
 
 int rt_render(rt_handle* h, const rt_params* params) { return render_impl(h, params, 0, 1); }
 
+int rt_render_frames(rt_handle* h, const rt_params* params, uint32_t n_frames) {
+    return render_frames_impl(h, params, n_frames, 0, 1);
+}
+
 int rt_render_strips(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world) {
     return render_impl(h, params, rank, world);
+}
+
+int rt_render_strips_frames(rt_handle* h, const rt_params* params, uint32_t n_frames, uint32_t rank, uint32_t world) {
+    return render_frames_impl(h, params, n_frames, rank, world);
 }
 
 int rt_assemble_strips(rt_handle* h, const void* gathered_device, uint32_t width, uint32_t height, uint32_t world) {
@@ -918,14 +1078,28 @@ int rt_assemble_strips(rt_handle* h, const void* gathered_device, uint32_t width
     return RT_OK;
 }
 
-int rt_render_multi(rt_handle** per_gpu, int n_gpus, const rt_params* params, float* rgba32f_out) {
+// ---- multi-GPU frame in one process ------------------------------------------------------------
+// Gather transport between distinct devices: RCCL (grouped ncclSend / ncclRecv = a gather: every peer
+// sends over its own xGMI link to the root), loaded on first use -- librccl is ~570 MB and no other
+// entry point needs it.
+static int render_multi_impl(rt_handle** per_gpu, int n_gpus, const rt_params* params, uint32_t n_frames,
+                             float* rgba32f_out) {
     if (!per_gpu || n_gpus < 1 || !params) return RT_ERR_INVALID_ARGUMENT;
     for (int r = 0; r < n_gpus; ++r)
         if (!per_gpu[r]) return RT_ERR_INVALID_ARGUMENT;
     rt_handle* root = per_gpu[0];
+    if (n_frames == 0) return RT_OK;
     const uint32_t world = (uint32_t)n_gpus;
     const uint64_t pad = rt_strip_texels(params->width, params->height, 0, world);
     const uint64_t frame_texels = (uint64_t)params->width * params->height;
+    // transport: RCCL between distinct devices (option "multi_rccl" = 1, default), device-to-device
+    // copies when several handles share a device (tests) or when the option is 0; 2 forces RCCL on a
+    // one-handle "node" (exercises the RCCL path on a single-GPU box)
+    bool distinct = true;
+    for (int r = 0; r < n_gpus; ++r)
+        for (int q = 0; q < r; ++q)
+            if (per_gpu[r]->device == per_gpu[q]->device) distinct = false;
+    const bool use_rccl = distinct && ((root->multi_rccl == 1 && n_gpus > 1) || root->multi_rccl == 2);
     // root-side staging, grown on demand
     HIP_TRY(root, hipSetDevice(root->device));
     if (root->multi_gathered_texels < pad * world) {
@@ -940,34 +1114,85 @@ int rt_render_multi(rt_handle** per_gpu, int n_gpus, const rt_params* params, fl
         HIP_TRY(root, hipMalloc((void**)&root->multi_frame, frame_texels * sizeof(float4)));
         root->multi_frame_texels = frame_texels;
     }
-    // 1. every GPU renders its strips (asynchronous, in parallel across devices)
+    while (root->multi_copied_events.size() < (size_t)n_gpus) {  // events of the root's device, one per rank
+        hipEvent_t e = nullptr;
+        HIP_TRY(root, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        root->multi_copied_events.push_back(e);
+    }
+    if (use_rccl) {
+        std::vector<int> devs(n_gpus);
+        for (int r = 0; r < n_gpus; ++r) devs[r] = per_gpu[r]->device;
+        if (root->multi_comm_devices != devs) {
+            if (!g_rccl.load()) return fail(root, RT_ERR_DEVICE, g_rccl.why + " (option multi_rccl = 0 selects device-to-device copies)");
+            multi_drop_comms(root);
+            std::vector<ncclComm_t> comms(n_gpus);
+            NCCL_TRY(root, g_rccl.CommInitAll(comms.data(), n_gpus, devs.data()));
+            for (ncclComm_t c : comms) root->multi_comms.push_back((void*)c);
+            root->multi_comm_devices = devs;
+        }
+    } else {
+        // peer access for the device-to-device copies (without it the runtime stages them through the host)
+        for (int r = 1; r < n_gpus; ++r) {
+            const int peer = per_gpu[r]->device;
+            if (peer == root->device || root->multi_peers_enabled.count(peer)) continue;
+            int can = 0;
+            HIP_TRY(root, hipDeviceCanAccessPeer(&can, root->device, peer));
+            if (can) {
+                hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+                if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                else if (e != hipSuccess) return fail(root, RT_ERR_DEVICE, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+            }
+            root->multi_peers_enabled.insert(peer);
+        }
+    }
+    // 1. every GPU renders its strips (asynchronous, in parallel across devices).  render_impl makes a
+    //    rank's stream wait until the root has finished copying that rank's previous frame.
     for (int r = 0; r < n_gpus; ++r) {
-        int rc = render_impl(per_gpu[r], params, (uint32_t)r, world);
+        int rc = render_frames_impl(per_gpu[r], params, n_frames, (uint32_t)r, world);
         if (rc != RT_OK) {
             if (per_gpu[r] != root) root->err = "rank " + std::to_string(r) + ": " + per_gpu[r]->err;
             return rc;
         }
     }
-    // 2. gather: the root's stream waits for each rank's render, then pulls its strips
-    //    (device-to-device over xGMI; each peer uses its own link to the root)
-    for (int r = 0; r < n_gpus; ++r) {
-        rt_handle* h = per_gpu[r];
+    // 2. gather: one transfer per rank into the root's [world][pad] buffer
+    auto rank_texels = [&](int r) {
         // world == 1: the "strips" are the frame itself (no padding of a ragged last strip)
-        const uint64_t n = world == 1 ? frame_texels : rt_strip_texels(params->width, params->height, (uint32_t)r, world);
-        if (n == 0) continue;
-        {
+        return world == 1 ? frame_texels : rt_strip_texels(params->width, params->height, (uint32_t)r, world);
+    };
+    if (use_rccl) {
+        NCCL_TRY(root, g_rccl.GroupStart());
+        for (int r = 0; r < n_gpus; ++r) {
+            rt_handle* h = per_gpu[r];
+            const uint64_t n = rank_texels(r);
+            if (n == 0) continue;
+            NCCL_TRY(root, g_rccl.Send(h->image, n * 4, ncclFloat, 0, (ncclComm_t)root->multi_comms[r], h->stream));
+            NCCL_TRY(root, g_rccl.Recv(root->multi_gathered + (size_t)r * pad, n * 4, ncclFloat, r, (ncclComm_t)root->multi_comms[0], root->stream));
+        }
+        NCCL_TRY(root, g_rccl.GroupEnd());
+        // (a rank's send is ordered on its own stream before its next render: no extra event needed)
+    } else {
+        for (int r = 0; r < n_gpus; ++r) {
+            rt_handle* h = per_gpu[r];
+            const uint64_t n = rank_texels(r);
+            if (n == 0) continue;
             HIP_TRY(h, hipSetDevice(h->device));
             if (!h->multi_event) HIP_TRY(h, hipEventCreateWithFlags(&h->multi_event, hipEventDisableTiming));
             HIP_TRY(h, hipEventRecord(h->multi_event, h->stream));
             HIP_TRY(root, hipSetDevice(root->device));
             HIP_TRY(root, hipStreamWaitEvent(root->stream, h->multi_event, 0));
+            if (h->device == root->device)
+                HIP_TRY(root, hipMemcpyAsync(root->multi_gathered + (size_t)r * pad, h->image, n * sizeof(float4),
+                                             hipMemcpyDeviceToDevice, root->stream));
+            else
+                HIP_TRY(root, hipMemcpyPeerAsync(root->multi_gathered + (size_t)r * pad, root->device, h->image, h->device,
+                                                 n * sizeof(float4), root->stream));
+            if (h->stream != root->stream) {
+                // the rank's next render overwrites h->image: it has to wait for this copy
+                HIP_TRY(root, hipEventRecord(root->multi_copied_events[r], root->stream));
+                h->multi_copied = root->multi_copied_events[r];
+                h->multi_copy_pending = true;
+            }
         }
-        if (h->device == root->device)
-            HIP_TRY(root, hipMemcpyAsync(root->multi_gathered + (size_t)r * pad, h->image, n * sizeof(float4),
-                                         hipMemcpyDeviceToDevice, root->stream));
-        else
-            HIP_TRY(root, hipMemcpyPeerAsync(root->multi_gathered + (size_t)r * pad, root->device, h->image, h->device,
-                                             n * sizeof(float4), root->stream));
     }
     // 3. assemble on the root and (optionally) read back
     HIP_TRY(root, hipSetDevice(root->device));
@@ -978,6 +1203,24 @@ int rt_render_multi(rt_handle** per_gpu, int n_gpus, const rt_params* params, fl
                                      hipMemcpyDeviceToHost, root->stream));
         HIP_TRY(root, hipStreamSynchronize(root->stream));
     }
+    return RT_OK;
+}
+
+int rt_render_multi(rt_handle** per_gpu, int n_gpus, const rt_params* params, float* rgba32f_out) {
+    return render_multi_impl(per_gpu, n_gpus, params, 1, rgba32f_out);
+}
+
+int rt_render_multi_frames(rt_handle** per_gpu, int n_gpus, const rt_params* params, uint32_t n_frames, float* rgba32f_out) {
+    return render_multi_impl(per_gpu, n_gpus, params, n_frames, rgba32f_out);
+}
+
+int rt_read_multi_frame(rt_handle* root, float* rgba32f_out, size_t bytes) {
+    if (!root || !rgba32f_out) return fail(root, RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!root->multi_frame || bytes > root->multi_frame_texels * sizeof(float4))
+        return fail(root, RT_ERR_INVALID_ARGUMENT, "no assembled frame of that size");
+    HIP_TRY(root, hipSetDevice(root->device));
+    HIP_TRY(root, hipMemcpyAsync(rgba32f_out, root->multi_frame, bytes, hipMemcpyDeviceToHost, root->stream));
+    HIP_TRY(root, hipStreamSynchronize(root->stream));
     return RT_OK;
 }
 
@@ -1020,14 +1263,15 @@ int rt_get_stats(rt_handle* h, rt_stats* out) {
     out->node_tests = c.node_tests;
     out->triangle_tests = c.triangle_tests;
     // counters accumulate over all launches since rt_reset_timing
-    float total = 0.0f;
+    double total = h->ev_ms_harvested;
     for (size_t i = 0; i < h->ev_used; ++i) {
         float ms = 0.0f;
         HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
         total += ms;
     }
-    out->kernel_ms = total;
-    out->launches = (uint32_t)h->ev_used;
+    out->kernel_ms = (float)total;
+    out->launches = (uint32_t)h->launches_total;
+    out->frames = (uint32_t)h->frames_total;
     return RT_OK;
 }
 
@@ -1037,6 +1281,8 @@ int rt_reset_timing(rt_handle* h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(Counters), h->stream));
     h->ev_used = 0;
+    h->ev_ms_harvested = 0.0;
+    h->launches_total = h->frames_total = 0;
     h->paths_total = 0;
     return RT_OK;
 }
@@ -1045,8 +1291,13 @@ int rt_set_stream(rt_handle* h, void* hip_stream) {
     if (!h) return RT_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->ev_used; ++i) {  // (the old stream is idle: its recorded times are final)
+        float ms = 0.0f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+        h->ev_ms_harvested += ms;
+    }
+    h->ev_used = 0;
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
-    h->ev_used = 0;  // recorded events belong to the old stream's timeline
     return RT_OK;
 }
 

@@ -152,6 +152,23 @@ struct RenderArgs {
     uint32_t lds_scene;         // 1 => the blob is staged into LDS
     uint32_t forest_cull;       // 1 => forest members are skipped when the ray misses their root box
     uint32_t cull_roots;        // 1 => skip a mesh with an internal root when the ray misses the root box
+    // Frame batch (rt_render_frames): one persistent launch renders frames params.frames ..
+    // params.frames + batch_frames - 1; work items are (frame, tile) pairs, frame k's samples go
+    // unblended to image + k * batch_stride and rt_blend_frames_kernel applies wgsl:154-161 in frame
+    // order afterwards.  0 = a plain one-frame launch that blends in place.
+    uint32_t batch_frames;
+    unsigned long long batch_stride;  // texels between the scratch frames
+};
+
+constexpr uint32_t RT_MAX_BATCH_FRAMES = 32;
+// rt_blend_frames_kernel: image = the accumulation image, scratch = batch frame 0
+struct BlendArgs {
+    float4* image;
+    const float4* scratch;
+    unsigned long long texels, stride;
+    uint32_t n;
+    int32_t frames0;  // Params.frames of batch frame 0
+    float weight[RT_MAX_BATCH_FRAMES], rest[RT_MAX_BATCH_FRAMES];  // wgsl:157-158 per frame, from the host
 };
 
 }  // namespace rtd

@@ -828,9 +828,12 @@ DEV PixelCoord pixel_of(const A& a, uint32_t tile, uint32_t w) {
 
 // wgsl:154-161
 template <class A>
-DEV void store_texel(const A& a, uint32_t x, uint32_t out_row, f4 cur) {
+DEV void store_texel(const A& a, uint32_t x, uint32_t out_row, uint32_t batch_frame, f4 cur) {
     float4* texel = a.image + (size_t)out_row * a.params.width + x;
-    if (a.params.frames >= 1) {
+    if (a.batch_frames != 0u) {
+        // frame batch: the sample goes to its frame's scratch image; rt_blend_frames_kernel blends in frame order
+        texel[(size_t)batch_frame * a.batch_stride] = make_float4(cur.x, cur.y, cur.z, cur.w);
+    } else if (a.params.frames >= 1) {
         float4 prev = *texel;
         // wgsl:157: weight = 1 / f32(frames + 1), evaluated once per launch by the host with the
         // same two operations (RenderArgs::blend_weight, ::blend_rest)
@@ -917,6 +920,7 @@ struct PixelState {
     int32_t seg;
     bool fresh;
     uint32_t meta;         // rays of this pixel so far (bits 0-15, saturating) | cost-table slot (bits 16-18)
+                           // | index of the pixel's frame inside a frame batch (bits 19-31)
 };
 
 // wgsl:479-482: the pixel's focus point
@@ -934,12 +938,13 @@ DEV uint32_t frame_row_of(const A& a, uint32_t out_row) {
     return a.strip_world > 1u ? ((out_row >> 3) * a.strip_world + a.strip_rank) * 8u + (out_row & 7u) : out_row;
 }
 
-// wgsl:475 for pixel (x, y) of the full frame
+// wgsl:475 for pixel (x, y) of the full frame; batch_frame = index of the frame inside a frame batch
+// (Params.frames advances by one per frame, app.rs:44-53)
 template <bool LDS, class A>
 DEV void pixel_begin(const A& a, const CameraConsts& c, PixelState& s, uint32_t* ls, uint32_t x,
-                     uint32_t y, uint32_t out_row) {
+                     uint32_t y, uint32_t out_row, uint32_t batch_frame = 0u) {
     const float fx = (float)x, fy = (float)y;
-    const int32_t fr = a.params.frames;
+    const int32_t fr = (int32_t)((uint32_t)a.params.frames + batch_frame);
     const uint32_t absf = fr < 0 ? 0u - (uint32_t)fr : (uint32_t)fr;
     s.rng = (uint32_t)(fy * c.sx + fx) + absf * 719393u;
     s.x = x;
@@ -1281,8 +1286,9 @@ DEV void pixel_finish(const A& a, const PixelState& s, const uint32_t* ls) {
     // wgsl:498: total / f32(rays_per_pixel).  When the count is a power of two its reciprocal is
     // exact, and x * (1/n) and x / n are the same real number rounded once: the same float.
     const float r = a.spp_reciprocal;  // 0: not a power of two
-    if (r != 0.0f) store_texel(a, s.x, s.out_row, f4{total.x * r, total.y * r, total.z * r, total.w * r});
-    else store_texel(a, s.x, s.out_row, f4{total.x / n, total.y / n, total.z / n, total.w / n});
+    const uint32_t bf = s.meta >> 19;
+    if (r != 0.0f) store_texel(a, s.x, s.out_row, bf, f4{total.x * r, total.y * r, total.z * r, total.w * r});
+    else store_texel(a, s.x, s.out_row, bf, f4{total.x / n, total.y / n, total.z / n, total.w / n});
 }
 
 // Tile-cost feedback (rays per 8x8 tile, read by the next frame's scheduler).  A persistent
@@ -1381,6 +1387,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
     const bool have_samples = a.params.rays_per_pixel > 0;
 
     uint32_t pool_base = 0, pool_left = 0;  // wave-uniform: pixels left in the current tile
+    uint32_t pool_frame = 0;                // wave-uniform: the current tile's frame inside a frame batch
+    const uint32_t n_items = n_tiles * (a.batch_frames ? a.batch_frames : 1u);  // (frame, tile) pairs, frame-major
     bool exhausted = false;
     PixelState s;
     pixel_begin<(LDS && RT_TOTAL_IN_LDS)>(a, camera_consts(a), s, ls, 0, 0, 0);
@@ -1401,14 +1409,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                 uint32_t t = 0;
                 if (lane == 0) t = atomicAdd(a.work_counter, 1u);
                 t = __builtin_amdgcn_readfirstlane(t);
-                if (t >= n_tiles) {
+                if (t >= n_items) {
                     exhausted = true;
                 } else {
-                    if (a.tile_order) t = a.tile_order[t];  // heaviest tiles first (last frame's cost)
+                    pool_frame = 0u;
+                    if (a.batch_frames != 0u) {
+                        pool_frame = t / n_tiles;
+                        t -= pool_frame * n_tiles;
+                    }
+                    if (a.tile_order) t = a.tile_order[t];  // heaviest tiles first (an earlier frame's cost)
                     pool_base = t * 64u;
                     pool_left = 64u;
                     pull_seq += 1;
-                    if (a.tile_cost && lane == 0) tile_cost_pull(a, cost_tbl, pull_seq & (COST_SLOTS - 1u), t);
+                    // (a batch records the costs of its first frame)
+                    if (a.tile_cost && lane == 0 && pool_frame == 0u) tile_cost_pull(a, cost_tbl, pull_seq & (COST_SLOTS - 1u), t);
                 }
             }
             if (pool_left != 0) {
@@ -1421,14 +1435,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                     if (px.valid) {
                         DIAG(15);
                         const CameraConsts cam = camera_consts(ca);
-                        pixel_begin<(LDS && RT_TOTAL_IN_LDS)>(ca, cam, s, ls, px.x, px.y, px.out_row);
+                        pixel_begin<(LDS && RT_TOTAL_IN_LDS)>(ca, cam, s, ls, px.x, px.y, px.out_row, pool_frame);
                         pixel_cache_begin(a, ca, cam, s, ls);
-                        s.meta = (pull_seq & (COST_SLOTS - 1u)) << 16;
+                        s.meta = ((pull_seq & (COST_SLOTS - 1u)) << 16) | (pool_frame << 19);
                         if (have_samples) {
                             active = true;
                         } else {
                             pixel_finish<(LDS && RT_TOTAL_IN_LDS)>(ca, s, ls);  // 0 / 0 = NaN, as the shader would store
-                            if (a.tile_cost) tile_cost_add(a, cost_tbl, s);
+                            if (a.tile_cost && pool_frame == 0u) tile_cost_add(a, cost_tbl, s);
                         }
                     }
                 }
@@ -1448,7 +1462,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
             if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, node_tests, tri_tests)) {
                 DIAG(16);
                 pixel_finish<(LDS && RT_TOTAL_IN_LDS)>(cold_args(), s, ls);
-                if (a.tile_cost) tile_cost_add(a, cost_tbl, s);
+                if (a.tile_cost && (s.meta >> 19) == 0u) tile_cost_add(a, cost_tbl, s);
                 active = false;
             }
         }
@@ -1545,7 +1559,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rt_debug_kernel(const RenderArg
         }
         default: break;
     }
-    store_texel(a, px.x, px.out_row, out);
+    store_texel(a, px.x, px.out_row, 0u, out);
     if (a.counters) {
         atomicAdd(&a.counters->segments, 1ull);
         atomicAdd(&a.counters->node_tests, (unsigned long long)s0);
@@ -1569,6 +1583,30 @@ __global__ void __launch_bounds__(256) rt_primary_kernel(const RenderArgs a, flo
     t[0] = constant_ray ? rd.x : __uint_as_float(0x7fc00000u);
     t[1] = rd.y;
     t[2] = rd.z;
+}
+
+// wgsl:154-161 for the frames of a batch, in frame order: the only dependency between frames is
+// this per-texel blend, so rt_render_frames samples all frames of a batch in ONE launch (their
+// samples land in scratch images) and this dense pass applies `prev * (1 - w) + cur * w` -- the same
+// two IEEE operations per component, weights from the host as in a one-frame launch -- frame by frame.
+__global__ void __launch_bounds__(256) rt_blend_frames_kernel(const BlendArgs b) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (i >= b.texels) return;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    bool have = false;
+    for (uint32_t k = 0; k < b.n; ++k) {
+        const float4 cur = b.scratch[(unsigned long long)k * b.stride + i];
+        const int32_t frames = (int32_t)((uint32_t)b.frames0 + k);
+        if (frames >= 1) {
+            if (!have) acc = b.image[i];  // the image an earlier launch left
+            const float w = b.weight[k], om = b.rest[k];
+            acc = make_float4(acc.x * om + cur.x * w, acc.y * om + cur.y * w, acc.z * om + cur.z * w, acc.w * om + cur.w * w);
+        } else {
+            acc = cur;
+        }
+        have = true;
+    }
+    if (have) b.image[i] = acc;
 }
 
 __global__ void rt_assemble_kernel(const float4* __restrict__ gathered, float4* __restrict__ image,
@@ -1693,6 +1731,12 @@ hipError_t launch_render(const RenderArgs& a, hipStream_t stream) {
         if (tlas) launch_variant<false, true>(a, ntiles, lds, stream);
         else launch_variant<false, false>(a, ntiles, lds, stream);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_blend_frames(const BlendArgs& b, hipStream_t stream) {
+    if (b.texels == 0 || b.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_blend_frames_kernel, dim3((uint32_t)((b.texels + 255u) / 256u)), dim3(256), 0, stream, b);
     return hipGetLastError();
 }
 

@@ -75,8 +75,15 @@ class RayTracer:
     def render(self, params):
         self._check(self._L.rt_render(self._h, C.byref(params)))
 
+    def render_frames(self, params, n_frames):
+        """n_frames consecutive frames (Params.frames advancing), sampled in batches of overlapped frames."""
+        self._check(self._L.rt_render_frames(self._h, C.byref(params), n_frames))
+
     def render_strips(self, params, rank, world):
         self._check(self._L.rt_render_strips(self._h, C.byref(params), rank, world))
+
+    def render_strips_frames(self, params, n_frames, rank, world):
+        self._check(self._L.rt_render_strips_frames(self._h, C.byref(params), n_frames, rank, world))
 
     # ---- data movement / bookkeeping ----------------------------------
     def synchronize(self):
@@ -131,13 +138,23 @@ class RayTracer:
         return int(self._L.rt_strip_texels(width, height, rank, world))
 
 
-def render_multi(tracers, params, read_back=True):
-    """rt_render_multi over a list of RayTracer (one per device, same scene on each):
-    returns the assembled frame (H, W, 4) f32 when read_back, else None."""
+def render_multi(tracers, params, read_back=True, n_frames=1):
+    """rt_render_multi(_frames) over a list of RayTracer (one per device, same scene on each):
+    returns the assembled frame (H, W, 4) f32 when read_back, else None (non-blocking)."""
     L = load()
     arr = (C.c_void_p * len(tracers))(*[t._h for t in tracers])
     out = np.empty((params.height, params.width, 4), np.float32) if read_back else None
-    rc = L.rt_render_multi(arr, len(tracers), C.byref(params), out.ctypes.data if read_back else None)
+    rc = L.rt_render_multi_frames(arr, len(tracers), C.byref(params), n_frames, out.ctypes.data if read_back else None)
     if rc < 0:
         raise RtError(rc, L.rt_last_error(tracers[0]._h).decode())
+    return out
+
+
+def read_multi_frame(root, width, height):
+    """The frame the last render_multi call assembled on the root (blocking)."""
+    L = load()
+    out = np.empty((height, width, 4), np.float32)
+    rc = L.rt_read_multi_frame(root._h, out.ctypes.data, out.nbytes)
+    if rc < 0:
+        raise RtError(rc, L.rt_last_error(root._h).decode())
     return out

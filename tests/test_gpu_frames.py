@@ -1,0 +1,206 @@
+"""Frame batches (rt_render_frames) and the multi-GPU entry points: the accumulated image after n
+overlapped frames must be bit-identical to n sequential rt_render calls with Params.frames advancing
+(app.rs:44-53 + wgsl:154-161), on one GPU, per strip, and through rt_render_multi."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def sequential(rt, tracer, w, h, bounces, spp, f0, n, start=None):
+    tracer.write_image(np.zeros((h, w, 4), np.float32) if start is None else start)
+    for f in range(f0, f0 + n):
+        tracer.render(rt.make_params(w, h, bounces, spp, skybox=1, frames=f))
+    return tracer.read_image(w, h)
+
+
+@pytest.fixture(scope="module")
+def sponza(rt):
+    from ray_tracer_2_amd import scenes
+    return rt.SceneArrays.from_scene(scenes.sponza_standin(200))
+
+
+@pytest.mark.parametrize("f0,n,batch", [(0, 8, 16), (0, 2, 16), (3, 20, 16), (1, 8, 3), (-1, 5, 16), (0, 33, 32), (5, 1, 16)])
+def test_render_frames_equals_sequential_frames(rt, tracer, cornell, f0, n, batch):
+    w, h = 200, 100
+    tracer.load_scene(cornell)
+    start = np.random.RandomState(f0 + n).rand(h, w, 4).astype(np.float32)   # an earlier accumulation
+    want = sequential(rt, tracer, w, h, 4, 4, f0, n, start)
+    tracer.set_option("batch_frames", batch)
+    try:
+        tracer.write_image(start)
+        tracer.reset_timing()
+        tracer.render_frames(rt.make_params(w, h, 4, 4, skybox=1, frames=f0), n)
+        got = tracer.read_image(w, h)
+        st = tracer.stats()
+    finally:
+        tracer.set_option("batch_frames", 16)
+    assert np.array_equal(bits(got), bits(want))
+    assert st.frames == n and st.launches == -(-n // batch) and st.paths == w * h * 4 * n
+
+
+def test_render_frames_against_the_oracle(rt, oracle, tracer, cornell):
+    w, h = 96, 54
+    tracer.load_scene(cornell)
+    ref = np.zeros((h, w, 4), np.float32)
+    segs = 0
+    for f in range(5):
+        ref, st = oracle.render(rt.make_params(w, h, 4, 8, skybox=1, frames=f), cornell, image=ref)
+        segs += st.segments
+    tracer.reset_timing()
+    tracer.render_frames(rt.make_params(w, h, 4, 8, skybox=1, frames=0), 5)
+    assert np.array_equal(bits(tracer.read_image(w, h)), bits(ref))
+    assert tracer.stats().segments == segs
+
+
+@pytest.mark.parametrize("kw", [dict(lds_scene=0), dict(pixel_cache=0), dict(pixel_cache=2), dict(tile_feedback=0)])
+def test_render_frames_under_every_kernel_option(rt, tracer, cornell, kw):
+    w, h = 160, 90
+    tracer.load_scene(cornell)
+    want = sequential(rt, tracer, w, h, 4, 8, 0, 12)
+    (k, v), = kw.items()
+    tracer.set_option(k, v)
+    try:
+        tracer.write_image(np.zeros((h, w, 4), np.float32))
+        # two batches of 6: the second one runs with the tile order the first one's costs gave
+        tracer.set_option("batch_frames", 6)
+        tracer.render_frames(rt.make_params(w, h, 4, 8, skybox=1, frames=0), 12)
+        got = tracer.read_image(w, h)
+    finally:
+        tracer.set_option(k, {"lds_scene": 1, "pixel_cache": 1, "tile_feedback": 1}[k])
+        tracer.set_option("batch_frames", 16)
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_render_frames_many_mesh_textured_scene(rt, tracer, sponza):
+    """config 4's shape (many textured meshes under one transform, top-level tree kernels)."""
+    w, h = 192, 108
+    tracer.load_scene(sponza)
+    want = sequential(rt, tracer, w, h, 3, 2, 0, 6)
+    tracer.write_image(np.zeros((h, w, 4), np.float32))
+    tracer.render_frames(rt.make_params(w, h, 3, 2, skybox=1, frames=0), 6)
+    assert np.array_equal(bits(tracer.read_image(w, h)), bits(want))
+
+
+def test_debug_views_and_empty_batches_take_the_single_frame_path(rt, tracer, cornell):
+    w, h = 64, 36
+    tracer.load_scene(cornell)
+    for f in range(3):   # (a debug view is blended like any frame, wgsl:154-161)
+        tracer.render(rt.make_params(w, h, 4, 1, debug_flag=2, debug_scale=8, frames=f))
+    want = tracer.read_image(w, h)
+    tracer.write_image(np.zeros((h, w, 4), np.float32))
+    tracer.render_frames(rt.make_params(w, h, 4, 1, debug_flag=2, debug_scale=8, frames=0), 3)
+    assert np.array_equal(bits(tracer.read_image(w, h)), bits(want))
+    tracer.render_frames(rt.make_params(w, h, 4, 1), 0)   # nothing happens
+    assert np.array_equal(bits(tracer.read_image(w, h)), bits(want))
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "sponza"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_strip_frames_assemble_to_the_full_frames(rt, tracer, cornell, sponza, scene_name, world):
+    """rt_render_strips_frames per rank + rt_assemble_strips == rt_render over the same frames."""
+    arrays = cornell if scene_name == "cornell" else sponza
+    w, h, spp, nb, n = 200, 100, 2, 3, 5   # 13 strips, ragged last strip
+    tracer.load_scene(arrays)
+    full = sequential(rt, tracer, w, h, nb, spp, 0, n)
+    pad = tracer.strip_texels(w, h, 0, world)
+    gathered = np.zeros((world, pad, 4), np.float32)
+    small = rt.RayTracer(0, w, h)
+    small.load_scene(arrays)
+    for r in range(world):
+        small.write_image(np.zeros((h, w, 4), np.float32))
+        small.render_strips_frames(rt.make_params(w, h, nb, spp, skybox=1, frames=0), n, r, world)
+        cnt = small.strip_texels(w, h, r, world)
+        gathered[r, :cnt] = small.read_texels(cnt)
+    stage = rt.RayTracer(0, world * pad, 1)
+    stage.write_image(gathered.reshape(1, world * pad, 4))
+    tracer.assemble_strips(stage.device_image_ptr, w, h, world)
+    assert np.array_equal(bits(tracer.read_image(w, h)), bits(full))
+    small.close()
+    stage.close()
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "sponza"])
+def test_render_multi_without_readback_between_frames(rt, tracer, cornell, sponza, scene_name):
+    """Several rt_render_multi calls back to back in the non-blocking mode (no host readback in
+    between), one read at the end: every rank's next render has to wait for the root's copy of its
+    previous strips (each handle has its own stream here, all on device 0)."""
+    arrays = cornell if scene_name == "cornell" else sponza
+    w, h, spp, nb = 320, 200, 2, 3
+    tracer.load_scene(arrays)
+    want = sequential(rt, tracer, w, h, nb, spp, 0, 6)
+    ranks = [rt.RayTracer(0, w, h) for _ in range(3)]
+    try:
+        for t in ranks:
+            t.load_scene(arrays)
+        for f in range(6):
+            rt.render_multi(ranks, rt.make_params(w, h, nb, spp, skybox=1, frames=f), read_back=False)
+        got = rt.read_multi_frame(ranks[0], w, h)
+        assert np.array_equal(bits(got), bits(want))
+        # and the same six frames as two overlapped batches of three
+        for t in ranks:
+            t.write_image(np.zeros((h, w, 4), np.float32))
+        rt.render_multi(ranks, rt.make_params(w, h, nb, spp, skybox=1, frames=0), read_back=False, n_frames=3)
+        got = rt.render_multi(ranks, rt.make_params(w, h, nb, spp, skybox=1, frames=3), read_back=True, n_frames=3)
+        assert np.array_equal(bits(got), bits(want))
+    finally:
+        for t in ranks:
+            t.close()
+
+
+def test_render_multi_gather_through_rccl(rt, tracer, cornell):
+    """The RCCL transport (grouped ncclSend/ncclRecv) on the one device this box has: a one-rank
+    communicator gathering from itself.  On a multi-GPU node the same code runs with one rank per device."""
+    w, h = 160, 90
+    tracer.load_scene(cornell)
+    want = sequential(rt, tracer, w, h, 4, 4, 0, 3)
+    t = rt.RayTracer(0, w, h)
+    try:
+        t.load_scene(cornell)
+        t.set_option("multi_rccl", 2)
+        for f in range(2):
+            rt.render_multi([t], rt.make_params(w, h, 4, 4, skybox=1, frames=f), read_back=False)
+        got = rt.render_multi([t], rt.make_params(w, h, 4, 4, skybox=1, frames=2), read_back=True)
+        assert np.array_equal(bits(got), bits(want))
+    finally:
+        t.close()
+
+
+@pytest.mark.skipif("__import__('torch').cuda.device_count() < 2")
+def test_render_multi_across_devices(rt, cornell):
+    """Only on a multi-GPU node: one handle per device, RCCL gather and (multi_rccl = 0) peer copies."""
+    import torch
+    n = min(torch.cuda.device_count(), 8)
+    w, h = 320, 200
+    single = rt.RayTracer(0, w, h)
+    single.load_scene(cornell)
+    want = sequential(rt, single, w, h, 4, 4, 0, 4)
+    single.close()
+    for transport in (1, 0):
+        ranks = [rt.RayTracer(d, w, h) for d in range(n)]
+        try:
+            for t in ranks:
+                t.load_scene(cornell)
+            ranks[0].set_option("multi_rccl", transport)
+            for f in range(3):
+                rt.render_multi(ranks, rt.make_params(w, h, 4, 4, skybox=1, frames=f), read_back=False)
+            got = rt.render_multi(ranks, rt.make_params(w, h, 4, 4, skybox=1, frames=3), read_back=True)
+            assert np.array_equal(bits(got), bits(want))
+        finally:
+            for t in ranks:
+                t.close()
+
+
+def test_timing_survives_the_event_pool_wrap(rt, tracer, cornell):
+    """More launches than the event pool holds: launches, frames, paths and kernel_ms keep counting."""
+    w, h = 8, 8
+    tracer.load_scene(cornell)
+    tracer.reset_timing()
+    n = 4096 + 50
+    for f in range(n):
+        tracer.render(rt.make_params(w, h, 1, 1, frames=f))
+    st = tracer.stats()
+    assert st.launches == n and st.frames == n and st.paths == 64 * n
+    assert st.kernel_ms > 0 and st.kernel_ms / n < 5.0
