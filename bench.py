@@ -4,25 +4,36 @@ path on CornellBox-Original at 1920x1080, 8 spp, 4 bounces (BASELINE.json
 configs[1]), on N GPUs of one node.
 
 A "step" is one frame: one pass of the hot path (wgsl `main`) over the whole
-image with `Params.frames` advancing 0, 1, 2, ... (progressive accumulation on,
-as the reference's App::update does).  1 ray = 1 path segment = one
-calculate_ray_collions call (wgsl:353), counted exactly on the device.
+image with `Params.frames` advancing by one per frame (progressive accumulation
+on, as the reference's App::update does).  1 ray = 1 path segment = one
+calculate_ray_collions call (wgsl:353), counted exactly on the device; the
+segments whose hit is taken from the per-pixel primary-ray memo (no traversal)
+are counted too and `Mrays_traversed/s` is reported beside the headline.
+
+The timed region renders K frames with rt_render_frames: frames are sampled in
+batches (default 16 per launch) by ONE persistent launch over (frame, tile) work
+items and blended in frame order by a dense second kernel -- bit-identical to K
+single-frame launches (tests/test_gpu_frames.py).  The single-frame
+(un-overlapped) latency and the first frame after a camera change are measured
+outside the timed region and reported as extra keys.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The frame
 is split into 8-row strips dealt round-robin to the ranks (strong scaling: the
-frame is fixed); every step each rank renders its strips and ONE gather over
-xGMI assembles the frame on rank 0.  value = rays of the whole frame, all
-ranks, per second of the slowest rank.
+frame is fixed); every batch each rank renders its strips and ONE gather over
+xGMI assembles the accumulated frame on rank 0.  value = rays of the whole
+frames, all ranks, per second of the slowest rank.
 
 Prints one JSON line on rank 0 (contract in the task statement), with
-`roofline` (compulsory HBM bytes per launch / measured kernel time against the
-8 TB/s peak -- this path is VALU/latency-bound, so the fraction is small by
-construction; `roofline_valu` gives the instruction-issue view) and
-`cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample).
+`roofline` (compulsory HBM bytes per launch / measured launch time against the
+8 TB/s peak -- this path is VALU-bound, so the fraction is small by
+construction; `roofline_valu` gives the instruction-issue view against the
+guide's peak) and `cpu_baseline` (the CPU oracle timed on the host cores on a
+bounded sample).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,7 +42,6 @@ sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, SPP, BOUNCES = 1920, 1080, 8, 4
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP32_VALU_PEAK_TFLOPS = 157.3
 
 
 def cpu_baseline(rt, arrays):
@@ -64,12 +74,14 @@ def cpu_baseline(rt, arrays):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the un-overlapped / first-frame measurements")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU-staged rehearsal on one GPU)")
+    ap.add_argument("--batch", type=int, default=16, help="frames per launch of rt_render_frames (1 = one launch per frame)")
     ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning; default: library default)")
     ap.add_argument("--blocks", type=int, default=None, help="persistent grid size (tuning)")
     args = ap.parse_args()
@@ -101,6 +113,7 @@ def main():
     arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
     tracer = rt.RayTracer(device=device, max_width=W, max_height=H)
     tracer.load_scene(arrays)
+    tracer.set_option("batch_frames", max(1, args.batch))
     if args.variant is not None:
         tracer.set_option("kernel_variant", args.variant)
     if args.blocks is not None:
@@ -126,12 +139,17 @@ def main():
             assembler.bind_image(frame.data_ptr(), H * W)
             assembler.set_stream(stream_ptr)
 
-    def step(f):
-        p = rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=f)
+    def render(f0, n):
+        """Frames f0 .. f0 + n - 1, in batches of --batch frames; N > 1: one gather + assemble per batch."""
+        p = rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=f0)
         if world == 1:
-            tracer.render(p)
-        else:
-            tracer.render_strips(p, rank, world)
+            tracer.render_frames(p, n)
+            return
+        done = 0
+        while done < n:
+            nb = min(max(1, args.batch), n - done)
+            p.frames = f0 + done
+            tracer.render_strips_frames(p, nb, rank, world)
             if args.backend == "nccl":
                 dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
             else:  # rehearsal: stage through the host
@@ -142,6 +160,7 @@ def main():
                     gathered.copy_(torch.stack(parts))
             if rank == 0:
                 assembler.assemble_strips(gathered.data_ptr(), W, H, world)
+            done += nb
 
     def fence():
         tracer.synchronize()
@@ -151,15 +170,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for f in range(args.warmup):
-        step(f)
+    render(0, args.warmup)
     fence()
     tracer.reset_timing()
     t0 = time.perf_counter()
-    for f in range(args.warmup, args.warmup + args.steps):
-        step(f)
+    render(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    st = tracer.stats()
 
     if world > 1 and rank == 0 and os.environ.get("RT2_BENCH_VERIFY"):
         # the stitched frame must equal the single-GPU frame (same frames sequence)
@@ -171,71 +189,124 @@ def main():
         same = torch.equal(ref.view(torch.int32), frame.cpu().view(torch.int32))
         print(f"[verify] stitched frame bit-identical to 1-GPU frame: {same}", file=sys.stderr, flush=True)
         assert same
-    st = tracer.stats()
-    rays_local = float(st.segments)
-    kernel_ms = st.kernel_ms / max(st.launches, 1)
+    rays_local, reused_local = float(st.segments), float(st.segments_reused)
+    launch_ms = st.kernel_ms / max(st.launches, 1)     # render (+ blend) launch, HIP events on the tracer's stream
+    frames_per_launch = st.frames / max(st.launches, 1)
     if world > 1:
-        t = torch.tensor([elapsed, rays_local, kernel_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed, rays_local, launch_ms, reused_local], dtype=torch.float64,
+                         device="cuda" if args.backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, rays, kernel_ms = float(tmax[0]), float(t[1]), float(tmax[2])
+        elapsed, rays, launch_ms, reused = float(tmax[0]), float(t[1]), float(tmax[2]), float(t[3])
     else:
-        rays = rays_local
+        rays, reused = rays_local, reused_local
+
+    extras = {}
+    if world == 1 and rank == 0 and not args.no_extras:
+        # (outside the timed region) one launch per frame, in-place blend: what a host that shows every frame sees
+        seq = []
+        for rep in range(3):
+            tracer.synchronize()
+            tracer.reset_timing()
+            t1 = time.perf_counter()
+            for f in range(64):
+                tracer.render(rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=1 + f))
+            tracer.synchronize()
+            seq.append((time.perf_counter() - t1) / 64 * 1e3)
+        s1 = tracer.stats()
+        extras["ms_per_frame_unoverlapped"] = statistics.median(seq)
+        extras["kernel_ms_unoverlapped"] = s1.kernel_ms / max(s1.launches, 1)
+        # first frame after a camera change at full size: natural tile order, primary-ray table rebuilt
+        cam_t = type(arrays.uniform.camera)
+        cam0 = cam_t.from_buffer_copy(bytes(arrays.uniform.camera))
+        firsts = []
+        for rep in range(5):
+            cam = cam_t.from_buffer_copy(bytes(cam0))
+            cam.cam_to_world[3][0] = cam0.cam_to_world[3][0] + 1e-3 * (rep + 1)
+            tracer.set_camera(cam)
+            tracer.synchronize()
+            t1 = time.perf_counter()
+            tracer.render(rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=0))
+            tracer.synchronize()
+            firsts.append((time.perf_counter() - t1) * 1e3)
+        tracer.set_camera(cam0)
+        extras["ms_first_frame_after_camera_change"] = statistics.median(firsts)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays / elapsed / 1e6
-        # compulsory bytes per launch: the frame's texels are read
-        # (frames >= 1) and written once, plus the scene once.
+        # compulsory bytes: per frame the frame's texels are read (frames >= 1) and
+        # written once, 32 B per pixel, plus the scene once per launch.
         scene_bytes = arrays.meshes.nbytes + arrays.nodes.nbytes + arrays.triangles.nbytes + arrays.spheres.nbytes
         texels = local_texels if world > 1 else W * H
-        algo_bytes = texels * 16 * 2 + scene_bytes
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-        # (profiles/run_profile.sh; FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024): PMC counters
-        # cannot be read from inside the process, so the figure is the profiled one or null.
-        traffic, traffic_src, valu = None, None, None
+        algo_bytes = texels * 16 * 2 * frames_per_launch + scene_bytes
+        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
+        # HBM traffic and VALU counters per launch come from the committed rocprofv3 PMC passes of this same
+        # command (profiles/run_profile.sh; PMC counters cannot be read from inside the process).  They
+        # are reported only when they were measured on the build that is running (source hash, batch).
+        traffic, traffic_src, valu, stale = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         if world == 1 and (W, H) == (WIDTH, HEIGHT) and os.path.exists(tpath):
+            from ray_tracer_2_amd.build import source_hash
             tj = json.load(open(tpath))
-            traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
-            if "valu_instructions_per_launch" in tj:
-                # the bound that matters: VALU issue.  Peak = the fastest plain VALU
-                # stream measured on this chip (tools/micro/issue_cost.hip: v_mul_f32, 8 waves/SIMD, one
-                # wave64 instruction per 3.0 cycles per SIMD; v_fma/v_min ~4); instruction count and clock
-                # come from the same rocprofv3 passes as the traffic.
-                simds = torch.cuda.get_device_properties(device).multi_processor_count * 4
-                clock = tj.get("shader_clock_ghz", 2.4)
-                rate = tj["valu_instructions_per_launch"] / (kernel_ms * 1e-3) / 1e9
-                valu = {"bound": "valu_issue", "achieved": rate, "peak": simds * clock / 3.0, "unit": "G wave-instructions/s",
-                        "frac": rate / (simds * clock / 3.0), "lane_utilisation": tj.get("valu_lane_utilisation"),
-                        "source": tj["source"].replace("FETCH_SIZE / WRITE_SIZE", "SQ_INSTS_VALU / GRBM_GUI_ACTIVE")}
+            if tj.get("source_hash") != source_hash() or tj.get("frames_per_launch") != frames_per_launch \
+                    or args.variant is not None or args.blocks is not None or os.environ.get("RT2_OPTIONS"):
+                stale = f"stale profile: {tj.get('source')} was taken on another build or batch size"
+            else:
+                traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
+                if "valu_instructions_per_launch" in tj:
+                    # The bound that matters: VALU issue.  Peak = the guide's: a SIMD-32
+                    # issues one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md; that is what
+                    # 157.3 TFLOP/s FP32 means).  issue_frac = wave-instructions issued / that peak;
+                    # useful_lane_frac = issue_frac x active lanes per instruction / 64.
+                    simds = torch.cuda.get_device_properties(device).multi_processor_count * 4
+                    clock = tj.get("shader_clock_ghz", 2.4)
+                    rate = tj["valu_instructions_per_launch"] / (launch_ms * 1e-3) / 1e9
+                    peak = simds * clock / 2.0
+                    lanes = tj.get("valu_lane_utilisation")
+                    valu = {"bound": "valu_issue", "achieved": rate, "peak": peak, "unit": "G wave-instructions/s",
+                            "peak_definition": "MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles per SIMD-32 x "
+                                               f"{simds} SIMDs x {clock:.2f} GHz (measured shader clock)",
+                            "frac": rate / peak, "issue_frac": rate / peak, "lane_utilisation": lanes,
+                            "useful_lane_frac": (rate / peak * lanes) if lanes else None,
+                            "measured_stream_peak": tj.get("measured_valu_stream_peak"),
+                            "source": tj["source"].replace("FETCH_SIZE / WRITE_SIZE", "SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU / GRBM_GUI_ACTIVE")}
+        # which kernel the library runs for this shape (rt_api.hip render_impl): batches always the persistent one
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        tiles = ((W + 7) // 8) * (texels // W // 8 if world > 1 else (H + 7) // 8)
+        kernel = "rt_render_persistent_kernel<true, false, false>"
+        if frames_per_launch == 1 and (args.variant == 1 or (args.variant is None and tiles * 4 <= cus * 20 * 5)):
+            kernel = "rt_render_tiles_kernel<true, false, false>"
         out = {
             "metric": "Mrays/s", "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "CornellBox-Original.obj/.mtl of the reference through the loader + BVH builder "
+                    "(committed as tests/golden/cornell_scene.npz); no random inputs: the seed is Params.frames",
             "config": {"workload": f"CornellBox-Original {W}x{H}, {SPP} spp, {BOUNCES} bounces "
                                    "(BASELINE configs[1]); 8 meshes / 32 triangles / 32 BVH nodes",
                        "frames": f"{args.warmup}..{args.warmup + args.steps - 1} (progressive accumulation)",
-                       "parallelism": "1 GPU" if world == 1 else f"8-row strips round-robin over {world} GPUs + 1 RCCL gather/frame",
-                       "rays_per_frame": rays / args.steps, "Mpaths/s": W * H * SPP * args.steps / elapsed / 1e6},
+                       "frames_overlapped": f"{frames_per_launch:g} frames per launch (rt_render_frames: (frame, tile) work items "
+                                            "+ ordered blend kernel; bit-identical to one launch per frame)"
+                                            if frames_per_launch > 1 else "no: one launch per frame",
+                       "parallelism": "1 GPU" if world == 1 else f"8-row strips round-robin over {world} GPUs + 1 RCCL gather per "
+                                                                 f"batch of {frames_per_launch:g} frames",
+                       "rays_per_frame": rays / args.steps,
+                       "rays_traversed_per_frame": (rays - reused) / args.steps,
+                       "Mrays_traversed/s": (rays - reused) / elapsed / 1e6,
+                       "Mpaths/s": W * H * SPP * args.steps / elapsed / 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "rt_render_persistent_kernel<true, false, false>", "kernel_ms": kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src or stale,
+                         "kernel": kernel, "kernel_ms": launch_ms, "frames_per_launch": frames_per_launch,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "path is FP32-VALU-issue-bound (SURVEY 8d, DESIGN.md): compulsory HBM bytes are ~66 MB/frame; "
-                                 "measured traffic also holds the 25 MB/frame primary-ray table (12 B/pixel, read once: it "
-                                 "replaces per-pixel ray set-up at 9 % lane utilisation) and 16-B texel stores that touch a "
-                                 "64-B sector more than once (pixels finish lane by lane)"},
+                         "note": "path is FP32-VALU-bound (SURVEY 8d, DESIGN.md): compulsory HBM bytes are 32 B per pixel per frame; "
+                                 "kernel_ms is the launch (render + ordered blend of the batch) from HIP events on the "
+                                 "tracer's stream"},
         }
         if valu is not None:
             out["roofline_valu"] = valu
-        # which kernel the library's automatic choice runs for this shape (rt_api.hip render_impl)
-        cus = torch.cuda.get_device_properties(device).multi_processor_count
-        tiles = ((W + 7) // 8) * (texels // W // 8 if world > 1 else (H + 7) // 8)
-        if args.variant == 1 or (args.variant is None and tiles * 4 <= cus * 16 * 5):
-            out["roofline"]["kernel"] = "rt_render_tiles_kernel<true, false, false>"
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, arrays)
         print(json.dumps(out), flush=True)

@@ -181,6 +181,9 @@ typedef struct rt_stats {
     float kernel_ms;         /* sum of the hipEvent times of `launches` render launches */
     uint32_t launches;       /* render launches since the last rt_reset_timing */
     uint32_t frames;         /* frames those launches rendered (rt_render_frames: several per launch) */
+    uint64_t segments_reused; /* of `segments`: primary segments whose hit was taken from the per-pixel memo
+                               * (same ray as the pixel's first sample: no traversal ran); segments -
+                               * segments_reused rays were traversed */
 } rt_stats;
 
 /* ≙ RayTracer::new + create_gpu_resources (ray_tracer.rs:49,316): picks the

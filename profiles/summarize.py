@@ -2,15 +2,25 @@
 """Distil a gpurun_out/prof_<tag>/ directory (profiles/run_profile.sh) into the
 text summary committed as profiles/<tag>_summary.txt.
 
+    python3 profiles/summarize.py gpurun_out/prof_<tag> [--algorithmic-bytes-per-frame N] [--frames-per-launch K]
+                                  [--note "..."] [--no-latest]
+
 HBM traffic follows MI355X_MICROARCH.md section "HBM": FETCH_SIZE and WRITE_SIZE
 are collected in separate --pmc passes, are in KiB, and on gfx950 FETCH_SIZE
 reports half the bytes of a 16-B-per-lane coalesced read, so it is doubled.
+Counters are averaged per launch of the render kernel (the first launch -- warm-up, natural
+tile order -- is dropped); the blend kernel of a frame batch is listed beside it.
 """
+import argparse
 import collections
 import csv
 import glob
+import json
 import os
 import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
 
 
 def rows(pat):
@@ -21,57 +31,103 @@ def rows(pat):
 
 
 def main():
-    d = sys.argv[1]
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dir")
+    ap.add_argument("--algorithmic-bytes-per-frame", type=float, default=1920 * 1080 * 32 + 6528)
+    ap.add_argument("--frames-per-launch", type=int, default=16)
+    ap.add_argument("--note", default="")
+    ap.add_argument("--no-latest", action="store_true", help="do not rewrite profiles/latest_traffic.json (not the headline config)")
+    args = ap.parse_args()
+    d = args.dir
     tag = os.path.basename(d.rstrip("/")).replace("prof_", "")
-    lines = [f"rocprofv3 summary {tag}: python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline "
-             "(CornellBox-Original 1920x1080, 8 spp, 4 bounces, 1 x MI355X)", ""]
+    cmd = open(f"{d}/command.txt").read().strip() if os.path.exists(f"{d}/command.txt") else "?"
+    lines = [f"rocprofv3 summary {tag}: {cmd}", ""]
+    if args.note:
+        lines += [args.note, ""]
+    if os.path.exists(f"{d}/status.txt"):
+        lines += ["passes: " + "; ".join(l.strip() for l in open(f"{d}/status.txt")), ""]
     lines.append("== kernel-trace --stats (kernel_stats.csv) ==")
     for r in rows(f"{d}/trace/*/*_kernel_stats.csv"):
         lines.append(f"{r['Name'][:70]:70s} calls {r['Calls']:>4s}  avg {float(r['AverageNs']) / 1e3:10.1f} us  "
                      f"min {float(r['MinNs']) / 1e3:10.1f}  max {float(r['MaxNs']) / 1e3:10.1f}  {r['Percentage']}%")
-    tr = [r for r in rows(f"{d}/trace/*/*_kernel_trace.csv") if "rt_render" in r["Kernel_Name"]]
+    trace = rows(f"{d}/trace/*/*_kernel_trace.csv")
+    tr = [r for r in trace if "rt_render" in r["Kernel_Name"]]
+    bl = [r for r in trace if "rt_blend" in r["Kernel_Name"]]
+    dur = lambda rs: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs) / max(len(rs), 1) * 1e-9
     if tr:
         r = tr[-1]
         lines.append(f"render kernel: grid {r['Grid_Size_X']} x wg {r['Workgroup_Size_X']}, VGPR_Count {r['VGPR_Count']}, "
                      f"SGPR_Count {r['SGPR_Count']}, LDS_Block_Size {r['LDS_Block_Size']}, Scratch_Size {r['Scratch_Size']}")
+        steady = tr[1:] if len(tr) > 2 else tr
+        lines.append(f"render kernel, launches after the first: avg {dur(steady) * 1e6:.1f} us per launch = "
+                     f"{dur(steady) * 1e6 / args.frames_per_launch:.1f} us per frame ({args.frames_per_launch} frames per launch)"
+                     + (f"; blend kernel avg {dur(bl) * 1e6:.1f} us per launch" if bl else ""))
     lines.append("")
-    lines.append("== PMC passes (per render launch; mean over the accumulating launches, frames >= 1) ==")
-    agg = collections.OrderedDict()
+    lines.append("== PMC passes (mean per launch; render kernel: launches after the first) ==")
+    agg, agg_blend = collections.OrderedDict(), collections.OrderedDict()
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_l2"):
-        per = collections.defaultdict(list)
+        per, perb = collections.defaultdict(list), collections.defaultdict(list)
         for r in rows(f"{d}/{sub}/*/*_counter_collection.csv"):
             if "rt_render" in r["Kernel_Name"]:
                 per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            elif "rt_blend" in r["Kernel_Name"]:
+                perb[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in per.items():
-            v = v[1:] if len(v) > 2 else v  # drop the frames=0 launch (no image read)
+            v = v[1:] if len(v) > 2 else v
             agg[k] = sum(v) / len(v)
-            lines.append(f"{k:26s} {agg[k]:16.6g}   ({len(v)} launches)")
+            extra = ""
+            if k in perb:
+                agg_blend[k] = sum(perb[k]) / len(perb[k])
+                extra = f"   blend kernel {agg_blend[k]:14.6g}"
+            lines.append(f"{k:26s} {agg[k]:16.6g}   ({len(v)} launches){extra}")
     lines.append("")
+    rec = None
     if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
         fetch = agg["FETCH_SIZE"] * 1024 * 2  # KiB -> B, gfx950 x2 correction for 16 B/lane reads
         write = agg["WRITE_SIZE"] * 1024
-        import json
-        rec = {"bytes_per_launch": fetch + write, "source": f"profiles/{tag}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
-        if "SQ_INSTS_VALU" in agg:
-            rec["valu_instructions_per_launch"] = agg["SQ_INSTS_VALU"]
-        if "SQ_THREAD_CYCLES_VALU" in agg and "SQ_ACTIVE_INST_VALU" in agg:
-            rec["valu_lane_utilisation"] = agg["SQ_THREAD_CYCLES_VALU"] / (64 * agg["SQ_ACTIVE_INST_VALU"])
-        if "GRBM_GUI_ACTIVE" in agg and tr:
-            dur_ = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in tr) / len(tr) * 1e-9
-            rec["shader_clock_ghz"] = agg["GRBM_GUI_ACTIVE"] / 8 / dur_ / 1e9
-        json.dump(rec, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "latest_traffic.json"), "w"))
-        lines.append(f"HBM traffic per launch: read {fetch / 1e6:.1f} MB (FETCH_SIZE x 1024 x 2) + write {write / 1e6:.1f} MB "
-                     f"(WRITE_SIZE x 1024) = {(fetch + write) / 1e6:.1f} MB; algorithmic 66.4 MB")
+        bfetch = agg_blend.get("FETCH_SIZE", 0.0) * 1024 * 2
+        bwrite = agg_blend.get("WRITE_SIZE", 0.0) * 1024
+        total = fetch + write + bfetch + bwrite
+        algo = args.algorithmic_bytes_per_frame * args.frames_per_launch
+        from ray_tracer_2_amd.build import source_hash
+        rec = {"bytes_per_launch": total, "frames_per_launch": args.frames_per_launch, "source_hash": source_hash(),
+               "source": f"profiles/{tag}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
+        lines.append(f"HBM traffic per launch ({args.frames_per_launch} frames): render kernel read {fetch / 1e6:.1f} MB (FETCH_SIZE x 1024 x 2) + "
+                     f"write {write / 1e6:.1f} MB (WRITE_SIZE x 1024)"
+                     + (f"; blend kernel read {bfetch / 1e6:.1f} MB + write {bwrite / 1e6:.1f} MB" if agg_blend else "")
+                     + f" = {total / 1e6:.1f} MB = {total / args.frames_per_launch / 1e6:.1f} MB per frame; "
+                     f"algorithmic {algo / 1e6:.1f} MB per launch ({args.algorithmic_bytes_per_frame / 1e6:.1f} MB per frame) -> x{total / algo:.2f}")
     if "SQ_INSTS_VALU" in agg and "SQ_WAVES" in agg:
-        lines.append(f"VALU instructions per launch {agg['SQ_INSTS_VALU']:.4g}; per wave {agg['SQ_INSTS_VALU'] / agg['SQ_WAVES']:.0f}; "
+        lines.append(f"VALU instructions per launch {agg['SQ_INSTS_VALU']:.4g} ({agg['SQ_INSTS_VALU'] / args.frames_per_launch:.4g} per frame); "
+                     f"per wave {agg['SQ_INSTS_VALU'] / agg['SQ_WAVES']:.0f}; "
                      f"SALU {agg.get('SQ_INSTS_SALU', 0):.4g}; LDS {agg.get('SQ_INSTS_LDS', 0):.4g}; SMEM {agg.get('SQ_INSTS_SMEM', 0):.4g}")
+        if rec is not None:
+            rec["valu_instructions_per_launch"] = agg["SQ_INSTS_VALU"]
     if "SQ_THREAD_CYCLES_VALU" in agg and "SQ_ACTIVE_INST_VALU" in agg:
-        lines.append(f"VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = "
-                     f"{agg['SQ_THREAD_CYCLES_VALU'] / (64 * agg['SQ_ACTIVE_INST_VALU']):.3f}")
+        lu = agg["SQ_THREAD_CYCLES_VALU"] / (64 * agg["SQ_ACTIVE_INST_VALU"])
+        lines.append(f"VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = {lu:.3f}")
+        if rec is not None:
+            rec["valu_lane_utilisation"] = lu
+    if "SQ_WAIT_ANY" in agg and "SQ_WAVE_CYCLES" in agg:
+        lines.append(f"wave time: waiting (s_waitcnt) {agg['SQ_WAIT_ANY'] / agg['SQ_WAVE_CYCLES']:.1%}, issue stalls "
+                     f"{agg.get('SQ_WAIT_INST_ANY', 0) / agg['SQ_WAVE_CYCLES']:.1%}, issuing {agg.get('SQ_ACTIVE_INST_ANY', 0) / agg['SQ_WAVE_CYCLES']:.1%} "
+                     "(SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES; pmc_sq and pmc_sq2 are different runs)")
+    if "TCC_HIT_sum" in agg and "TCC_MISS_sum" in agg:
+        lines.append(f"L2 hit rate {agg['TCC_HIT_sum'] / (agg['TCC_HIT_sum'] + agg['TCC_MISS_sum']):.1%}")
     if "GRBM_GUI_ACTIVE" in agg and tr:
-        dur = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in tr) / len(tr) * 1e-9
-        lines.append(f"effective clock = GRBM_GUI_ACTIVE / 8 / kernel time = {agg['GRBM_GUI_ACTIVE'] / 8 / dur / 1e9:.2f} GHz")
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{tag}_summary.txt")
+        steady = tr[1:] if len(tr) > 2 else tr
+        clk = agg["GRBM_GUI_ACTIVE"] / 8 / dur(steady) / 1e9
+        lines.append(f"effective clock = GRBM_GUI_ACTIVE / 8 / kernel time = {clk:.2f} GHz")
+        if rec is not None:
+            rec["shader_clock_ghz"] = clk
+        if "SQ_INSTS_VALU" in agg:
+            simds = 1024
+            rate = agg["SQ_INSTS_VALU"] / dur(steady) / 1e9
+            lines.append(f"VALU issue: {rate:.0f} G wave-instructions/s = {rate / (simds * clk / 2):.2f} of the guide's peak "
+                         f"(one wave64 instruction per 2 cycles per SIMD x {simds} SIMDs x {clk:.2f} GHz = {simds * clk / 2:.0f} G/s)")
+    if rec is not None and not args.no_latest:
+        json.dump(rec, open(os.path.join(HERE, "latest_traffic.json"), "w"))
+    out = os.path.join(HERE, f"{tag}_summary.txt")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 

@@ -76,6 +76,18 @@ def build_product(force=False, extra_flags=(), out=None, jobs=4):
     return out
 
 
+def source_hash():
+    """Identity of the render kernels a profile was taken on: hash of the device sources and of this
+    file (the compile flags).  profiles/latest_traffic.json carries it; bench.py only reports counter
+    figures measured on the build it is running."""
+    import hashlib
+    hh = hashlib.sha1()
+    for f in ("rt_kernel.hip", "rt_api.hip", "rt_device.h", "rt_transc.h", "rt_texture.h"):
+        hh.update(open(os.path.join(CSRC, f), "rb").read())
+    hh.update(open(os.path.abspath(__file__), "rb").read())
+    return hh.hexdigest()[:16]
+
+
 def build_oracle(force=False):
     src = os.path.join(ROOT, "oracle", "shader_oracle.cpp")
     deps = [src] + [os.path.join(CSRC, h) for h in ("rt_transc.h", "rt_texture.h", "rt_srgb_lut.h")]

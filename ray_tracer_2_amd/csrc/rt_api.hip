@@ -1262,6 +1262,7 @@ int rt_get_stats(rt_handle* h, rt_stats* out) {
     out->paths = h->paths_total;
     out->node_tests = c.node_tests;
     out->triangle_tests = c.triangle_tests;
+    out->segments_reused = c.reused;
     // counters accumulate over all launches since rt_reset_timing
     double total = h->ev_ms_harvested;
     for (size_t i = 0; i < h->ev_used; ++i) {

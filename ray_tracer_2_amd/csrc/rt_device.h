@@ -115,6 +115,7 @@ struct Counters {
     unsigned long long paths;
     unsigned long long node_tests;
     unsigned long long triangle_tests;
+    unsigned long long reused;  // segments whose hit came from the primary-ray memo (no traversal)
 };
 
 // Kernel argument block (lives in kernarg SGPRs).

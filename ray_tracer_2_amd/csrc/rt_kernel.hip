@@ -1260,8 +1260,11 @@ DEV bool path_end(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t mod
 
 template <bool LDS, bool STATS, bool TLAS>
 DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
-                   int& node_tests, int& tri_tests) {
+                   uint32_t& n_reused_wave, int& node_tests, int& tri_tests) {
     const uint32_t mode = path_begin<STATS>(a, s, ls, starve);
+    // segments served from the memo, counted per wave (a scalar add): Mrays/s can then be stated for
+    // traversed rays as well
+    n_reused_wave += (uint32_t)__popcll(__ballot(mode == STEP_REUSE));
     if (mode == STEP_WAIT) return false;
     Hit hit;
     hit.hit = false;
@@ -1325,9 +1328,10 @@ DEV void tile_cost_add(const RenderArgs& a, uint32_t* tbl, const PixelState& s) 
 }
 
 template <bool STATS>
-DEV void flush_counters(const RenderArgs& a, uint32_t n_segments, int node_tests, int tri_tests) {
+DEV void flush_counters(const RenderArgs& a, uint32_t n_segments, uint32_t n_reused_wave, int node_tests, int tri_tests) {
     if (a.counters) {
         atomicAdd(&a.counters->segments, (unsigned long long)n_segments);
+        if (n_reused_wave != 0u && (threadIdx.x & 63u) == 0u) atomicAdd(&a.counters->reused, (unsigned long long)n_reused_wave);
         if (STATS) {
             atomicAdd(&a.counters->node_tests, (unsigned long long)node_tests);
             atomicAdd(&a.counters->triangle_tests, (unsigned long long)tri_tests);
@@ -1353,10 +1357,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     pixel_cache_begin(a, a, cam, s, ls);
     uint32_t starve = 0;
     bool active = valid && a.params.rays_per_pixel > 0;
-    uint32_t n_segments = 0;
+    uint32_t n_segments = 0, n_reused_wave = 0;
     int node_tests = 0, tri_tests = 0;
     while (active) {
-        if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, node_tests, tri_tests)) active = false;
+        if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, n_reused_wave, node_tests, tri_tests)) active = false;
     }
     if (valid) pixel_finish<(LDS && RT_TOTAL_IN_LDS)>(a, s, ls);
     if (a.tile_cost && tile_ok) {  // one store per wave: the tile's rays
@@ -1364,7 +1368,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
         for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
         if ((threadIdx.x & 63u) == 0u) a.tile_cost[tile] = sum;
     }
-    flush_counters<STATS>(a, n_segments, node_tests, tri_tests);
+    flush_counters<STATS>(a, n_segments, n_reused_wave, node_tests, tri_tests);
 }
 
 // Variant 0 (default): persistent waves with active-lane refill.  Each wave
@@ -1393,7 +1397,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
     PixelState s;
     pixel_begin<(LDS && RT_TOTAL_IN_LDS)>(a, camera_consts(a), s, ls, 0, 0, 0);
     bool active = false;
-    uint32_t n_segments = 0;
+    uint32_t n_segments = 0, n_reused_wave = 0;
     int node_tests = 0, tri_tests = 0;
     // this wave's tile-cost table sits behind the workgroup's traversal stacks
     uint32_t* cost_tbl = cost_table_of_wave<LDS>(a);
@@ -1459,7 +1463,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         }
         TIC(t15);
         if (active) {
-            if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, node_tests, tri_tests)) {
+            if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, n_reused_wave, node_tests, tri_tests)) {
                 DIAG(16);
                 pixel_finish<(LDS && RT_TOTAL_IN_LDS)>(cold_args(), s, ls);
                 if (a.tile_cost && (s.meta >> 19) == 0u) tile_cost_add(a, cost_tbl, s);
@@ -1468,7 +1472,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         }
         TOC(t15, 15);
     }
-    flush_counters<STATS>(a, n_segments, node_tests, tri_tests);
+    flush_counters<STATS>(a, n_segments, n_reused_wave, node_tests, tri_tests);
 #if defined(RT_DIAGT)
     if (lane < 24u) atomicAdd(&g_diag[40 + lane], g_tacc[threadIdx.x >> 6][lane]);
 #endif

@@ -1,12 +1,13 @@
 #!/bin/bash
 # VALU instruction count + kernel time of the headline bench under RT2_OPTIONS (A/B of knobs)
 set -e
+python3 -m ray_tracer_2_amd.build > /dev/null 2>&1   # no compile under the profiler
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-a}
 OUT=$REPO/gpurun_out/prof_valu_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $REPO/bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- $BENCH > $OUT/sq.log 2>&1
 python3 - "$OUT" <<'PY'
