@@ -294,6 +294,16 @@ int rt_set_counters(rt_handle* h, int enabled);
 void* rt_device_image(rt_handle* h);
 void* rt_stream(rt_handle* h);
 
+/* Test-only: the device's evaluation of the kernels' arithmetic building blocks, element-wise over
+ * host arrays of n floats (bit patterns for integer inputs/outputs).  fn: 0 log, 1 cos, 2 sin, 3 exp,
+ * 4 exp2, 5 log2, 6 pow(x,y), 7 acos, 8 atan2(x,y), 9 sqrt, 10 x/y, 11 rand() from RNG state bits x,
+ * 12 next_random_number of state x (bits), 13 trig_signbits(x) (bits), 14 rand_normal_dist() from
+ * state x, 15 f32(u32 bits x) * 2^-32, 16 normalize(x, y, x*y).x.  The second call filters one RGBA8 sRGB
+ * texture at n (u, v) pairs (wgsl:455 as csrc/rt_texture.h defines it). */
+int rt_test_device_units(rt_handle* h, int fn, const float* x, const float* y, float* out, uint64_t n);
+int rt_test_device_sample_texture(rt_handle* h, const rt_texture_desc* tex, const float* uv, float* rgba_out,
+                                  uint64_t n);
+
 const char* rt_last_error(rt_handle* h);
 void rt_destroy(rt_handle* h);
 

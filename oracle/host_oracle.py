@@ -202,16 +202,58 @@ def _half_area(mn, mx):
         return f32(f32(e[0] * e[1] + e[1] * e[2]) + e[0] * e[2])
 
 
+def fmin_self(a, b):
+    """f32::min as rustc compiles it on x86-64 (llvm.minnum -> `b < a ? b : a`, NaN self replaced by b): among
+    equal operands -- zeros of either sign -- SELF wins.  The Rust docs leave the zero sign open; the product's
+    C++ builder is compiled by the same LLVM lowering (std::fmin under clang), numpy's minimum would let the
+    second operand win."""
+    with np.errstate(all="ignore"):
+        return np.where((b < a) | np.isnan(a), b, a).astype(np.float32)
+
+
+def fmax_self(a, b):
+    with np.errstate(all="ignore"):
+        return np.where((b > a) | np.isnan(a), b, a).astype(np.float32)
+
+
+def _seq_min(v, init):
+    """fold of fmin_self over the rows of v in order, starting from `init` (bvh.rs:292-297 fit_bounds)."""
+    if len(v) == 0:
+        return np.full(3, init, f32)
+    m = v.min(0)
+    out = fmin_self(np.full(3, init, f32), m)
+    for k in range(3):
+        if out[k] == 0:   # the first zero met keeps its sign
+            z = v[v[:, k] == 0, k]
+            if len(z):
+                out[k] = z[0]
+    return out
+
+
+def _seq_max(v, init):
+    if len(v) == 0:
+        return np.full(3, init, f32)
+    m = v.max(0)
+    out = fmax_self(np.full(3, init, f32), m)
+    for k in range(3):
+        if out[k] == 0:
+            z = v[v[:, k] == 0, k]
+            if len(z):
+                out[k] = z[0]
+    return out
+
+
 def build_bvh(P):
     """P: (T, 3, 3) float32 triangle positions.  Returns (order, nodes) with
     nodes as dict rows (left, right, first, count, aabb_min, aabb_max) and
     `order` the permutation of triangles (bvh.rs:208-290, Quality::High)."""
     T = P.shape[0]
     cen = ((P[:, 0] + P[:, 1]) + P[:, 2]) * f32(1.0 / 3.0)
-    tmin = np.minimum(P[:, 0], np.minimum(P[:, 1], P[:, 2]))
-    tmax = np.maximum(P[:, 0], np.maximum(P[:, 1], P[:, 2]))
+    tmin = fmin_self(P[:, 0], fmin_self(P[:, 1], P[:, 2]))   # bvh.rs:237-238: v1.min(v2.min(v3))
+    tmax = fmax_self(P[:, 0], fmax_self(P[:, 1], P[:, 2]))
     order = np.arange(T)
-    nodes = [dict(left=0, right=0, first=0, count=T, mn=tmin.min(0), mx=tmax.max(0))]
+    big0, small0 = f32(np.finfo(np.float32).max), f32(np.finfo(np.float32).min)
+    nodes = [dict(left=0, right=0, first=0, count=T, mn=_seq_min(tmin, big0), mx=_seq_max(tmax, small0))]
 
     def evaluate_sah(axis, pos, start, count):
         idx = order[start:start + count]
@@ -252,11 +294,11 @@ def build_bvh(P):
             for i in range(start, start + n):
                 t = order[i]
                 if cen[t, axis] < split:
-                    lmn, lmx = np.minimum(lmn, tmin[t]), np.maximum(lmx, tmax[t])
+                    lmn, lmx = fmin_self(lmn, tmin[t]), fmax_self(lmx, tmax[t])
                     order[start + lc], order[i] = order[i], order[start + lc]
                     lc += 1
                 else:
-                    rmn, rmx = np.minimum(rmn, tmin[t]), np.maximum(rmx, tmax[t])
+                    rmn, rmx = fmin_self(rmn, tmin[t]), fmax_self(rmx, tmax[t])
             li, ri = len(nodes), len(nodes) + 1
             nodes.append(dict(left=0, right=0, first=start, count=lc, mn=lmn, mx=lmx))
             nodes.append(dict(left=0, right=0, first=start + lc, count=n - lc, mn=rmn, mx=rmx))

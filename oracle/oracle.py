@@ -117,16 +117,29 @@ def rand_sequence(seed, n):
 
 
 FN = {"log": 0, "cos": 1, "sin": 2, "exp": 3, "exp2": 4, "log2": 5, "pow": 6, "acos": 7,
-      "atan2": 8, "sqrt": 9, "div": 10}
+      "atan2": 8, "sqrt": 9, "div": 10, "rand": 11, "rng": 12, "trig_signbits": 13, "rand_normal_dist": 14,
+      "rand_convert": 15, "normalize_x": 16}
 
 
 def transc(fn, x, y=None):
     L = load()
-    x = np.ascontiguousarray(x, dtype=np.float32)
+    # (integer inputs -- RNG states, raw generator outputs -- travel as bit patterns)
+    x = np.ascontiguousarray(x)
+    x = x.view(np.float32) if x.dtype == np.uint32 else x.astype(np.float32, copy=False)
     y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float32)
     out = np.empty_like(x)
     L.oracle_transc(C.c_int(FN[fn]), C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data),
                     C.c_void_p(out.ctypes.data), C.c_size_t(x.size))
+    return out
+
+
+def export_rgba8(img):
+    """save_render_to_file's pixel loop (app.rs:408-460) on an (H, W, 4) f32 image -> (H, W, 4) u8."""
+    L = load()
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    h, w = img.shape[:2]
+    out = np.empty((h, w, 4), np.uint8)
+    L.oracle_export_rgba8(C.c_void_p(img.ctypes.data), C.c_uint32(w), C.c_uint32(h), C.c_void_p(out.ctypes.data))
     return out
 
 

@@ -12,7 +12,7 @@
 // PARITY UNPINNED: the reference has no tests, golden vectors or fixtures, and
 // neither its Rust host nor its WGSL shader can be built or run in the build
 // container (no cargo/rustc, no naga/wgpu, no Vulkan ICD).  The
-// oracle is pinned only by analytic checks (tests/test_oracle_analytic.py)
+// oracle is pinned only by analytic checks (tests/test_oracle_golden.py)
 // and by the fixtures it generated itself (tests/golden/, made by
 // tests/golden/make_golden.py).
 //
@@ -676,6 +676,17 @@ void oracle_transc(int fn, const float* x, const float* y, float* out, size_t n)
             case 8: out[i] = rtm::atan2_(x[i], y[i]); break;
             case 9: out[i] = rtm::sqrt_(x[i]); break;
             case 10: out[i] = x[i] / y[i]; break;
+            // (11-16: the RNG and helpers, state / integer values passed as bit patterns)
+            case 11: { uint32_t s = rtm::f2u(x[i]); out[i] = orc::rand_(&s); break; }
+            case 12: { uint32_t s = rtm::f2u(x[i]); out[i] = rtm::u2f(orc::next_random_number(&s)); break; }
+            case 13: {  // sign bits of cos and sin as the shader's functions give them (wgsl:202-206)
+                const uint32_t c = rtm::f2u(rtm::cos_(x[i])) >> 31, sn = rtm::f2u(rtm::sin_(x[i])) >> 31;
+                out[i] = rtm::u2f(c | (sn << 1));
+                break;
+            }
+            case 14: { uint32_t s = rtm::f2u(x[i]); out[i] = orc::rand_normal_dist(&s); break; }
+            case 15: out[i] = (float)rtm::f2u(x[i]) / 4294967295.0f; break;  // wgsl:165
+            case 16: out[i] = orc::normalize(orc::vec3{x[i], y[i], x[i] * y[i]}).x; break;
             default: out[i] = 0.0f;
         }
     }
@@ -684,6 +695,42 @@ void oracle_transc(int fn, const float* x, const float* y, float* out, size_t n)
 void oracle_sample_texture(const rt_texture_desc* t, const float* uv, float* out, size_t n) {
     rtm::TexView tv{t->rgba8, t->width, t->height};
     for (size_t i = 0; i < n; ++i) rtm::sample_bilinear(tv, orc::SRGB_LUT, uv[2 * i], uv[2 * i + 1], out + 4 * i);
+}
+
+// The pixel loop of save_render_to_file (src/core/app.rs:408-460), step by step as the reference does
+// it: rows top to bottom of the buffer, x REVERSED inside a row, per channel
+// (v.powf(1.0 / 2.2).clamp(0.0, 1.0) * 255.0) as u8 -- `as u8` truncates, saturates and maps NaN to 0 --
+// then flip_horizontal_in_place and flip_vertical_in_place (image 0.25.8).  The byte result depends on
+// the platform's powf (Rust's f32::powf is libm's powf, as is this one); the product's rt_export_rgba8
+// folds the two x reversals into none and writes the rows flipped directly.
+void oracle_export_rgba8(const float* rgba, uint32_t width, uint32_t height, uint8_t* out) {
+    std::vector<uint8_t> data;
+    data.reserve((size_t)width * height * 4);
+    auto to_byte = [](float v) -> uint8_t {
+        float p = powf(v, 1.0f / 2.2f);
+        // f32::clamp: NaN stays NaN (app.rs:443-446)
+        float c = p != p ? p : (p < 0.0f ? 0.0f : (p > 1.0f ? 1.0f : p));
+        float s = c * 255.0f;
+        if (s != s) return 0;          // Rust float -> int casts: NaN -> 0, saturating
+        if (s <= 0.0f) return 0;
+        if (s >= 255.0f) return 255;
+        return (uint8_t)s;
+    };
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t xr = 0; xr < width; ++xr) {
+            const uint32_t x = width - 1 - xr;  // (0..RENDER_SIZE.0).rev()
+            const float* p = rgba + ((size_t)y * width + x) * 4;
+            for (int c = 0; c < 4; ++c) data.push_back(to_byte(p[c]));
+        }
+    // flip_horizontal_in_place, then flip_vertical_in_place
+    auto px = [&](uint32_t x, uint32_t y) { return data.data() + ((size_t)y * width + x) * 4; };
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width / 2; ++x)
+            for (int c = 0; c < 4; ++c) std::swap(px(x, y)[c], px(width - 1 - x, y)[c]);
+    for (uint32_t y = 0; y < height / 2; ++y)
+        for (uint32_t x = 0; x < width; ++x)
+            for (int c = 0; c < 4; ++c) std::swap(px(x, y)[c], px(x, height - 1 - y)[c]);
+    memcpy(out, data.data(), data.size());
 }
 
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }

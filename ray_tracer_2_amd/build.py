@@ -76,6 +76,22 @@ def build_product(force=False, extra_flags=(), out=None, jobs=4):
     return out
 
 
+CLASS_DRIVER_SO = os.path.join(ROOT, "tests", "_build", "librt2_class_driver.so")
+
+
+def build_class_driver(force=False):
+    """tests/cpp/ray_tracer_class_driver.cpp: the C++ test driver of rt2::RayTracer / rt2::FrameParams,
+    linked against the product library (tests/test_gpu_cpp_class.py)."""
+    src = os.path.join(ROOT, "tests", "cpp", "ray_tracer_class_driver.cpp")
+    deps = [src, PRODUCT_SO] + [os.path.join(CSRC, h) for h in ("host/ray_tracer.hpp", "host/scene.h", "host/bvh.h")]
+    if not force and not _newer(CLASS_DRIVER_SO, deps):
+        return CLASS_DRIVER_SO
+    os.makedirs(os.path.dirname(CLASS_DRIVER_SO), exist_ok=True)
+    _run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), src,
+          "-L", os.path.dirname(PRODUCT_SO), "-lrt2_mi355x", "-Wl,-rpath,$ORIGIN/../../ray_tracer_2_amd", "-o", CLASS_DRIVER_SO])
+    return CLASS_DRIVER_SO
+
+
 def source_hash():
     """Identity of the render kernels a profile was taken on: hash of the device sources and of this
     file (the compile flags).  profiles/latest_traffic.json carries it; bench.py only reports counter

@@ -29,6 +29,9 @@ hipError_t launch_tile_order(const uint32_t* cost, uint32_t n_tiles, uint32_t ma
                              hipStream_t stream);
 hipError_t launch_primary(const RenderArgs& a, float* table, hipStream_t stream);
 hipError_t launch_blend_frames(const BlendArgs& b, hipStream_t stream);
+hipError_t launch_units(int fn, const float* x, const float* y, float* out, unsigned long long n, hipStream_t stream);
+hipError_t launch_units_texture(const uint8_t* rgba8, uint32_t width, uint32_t height, const float* srgb_lut, const float* uv,
+                                float* out, unsigned long long n, hipStream_t stream);
 hipError_t launch_assemble(const float4* gathered, float4* image, uint32_t width, uint32_t height,
                            uint32_t world, unsigned long long pad_texels, hipStream_t stream);
 #if defined(RT_DIAG) || defined(RT_DIAGT)
@@ -1334,6 +1337,48 @@ int rt_diag_read(rt_handle* h, unsigned long long* out64, int reset) {
     return RT_OK;
 }
 #endif
+
+// Test-only entry points (tests/test_gpu_device_units.py): evaluate the kernels' arithmetic building
+// blocks on the device, element-wise over host arrays.
+int rt_test_device_units(rt_handle* h, int fn, const float* x, const float* y, float* out, uint64_t n) {
+    if (!h || !x || !y || !out) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    const size_t bytes = (size_t)(n ? n : 1) * sizeof(float);
+    HIP_TRY(h, hipMalloc((void**)&dx, bytes));
+    HIP_TRY(h, hipMalloc((void**)&dy, bytes));
+    HIP_TRY(h, hipMalloc((void**)&dout, bytes));
+    HIP_TRY(h, hipMemcpyAsync(dx, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dy, y, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, launch_units(fn, dx, dy, dout, n, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out, dout, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_dev(dx);
+    free_dev(dy);
+    free_dev(dout);
+    return RT_OK;
+}
+
+int rt_test_device_sample_texture(rt_handle* h, const rt_texture_desc* tex, const float* uv, float* rgba_out, uint64_t n) {
+    if (!h || !tex || !tex->rgba8 || !uv || !rgba_out || tex->width == 0 || tex->height == 0)
+        return fail(h, RT_ERR_INVALID_ARGUMENT, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    uint8_t* dt = nullptr;
+    float *duv = nullptr, *dout = nullptr;
+    const size_t tb = (size_t)tex->width * tex->height * 4;
+    HIP_TRY(h, hipMalloc((void**)&dt, tb));
+    HIP_TRY(h, hipMalloc((void**)&duv, (size_t)(n ? n : 1) * 2 * sizeof(float)));
+    HIP_TRY(h, hipMalloc((void**)&dout, (size_t)(n ? n : 1) * 4 * sizeof(float)));
+    HIP_TRY(h, hipMemcpyAsync(dt, tex->rgba8, tb, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(duv, uv, n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, launch_units_texture(dt, tex->width, tex->height, h->srgb_lut, duv, dout, n, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(rgba_out, dout, n * 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_dev(dt);
+    free_dev(duv);
+    free_dev(dout);
+    return RT_OK;
+}
 
 void* rt_device_image(rt_handle* h) { return h ? (void*)h->image : nullptr; }
 void* rt_stream(rt_handle* h) { return h ? (void*)h->stream : nullptr; }

@@ -1744,6 +1744,72 @@ hipError_t launch_blend_frames(const BlendArgs& b, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Test-only: the device's evaluation of the implementation-defined builtins (rt_transc.h), IEEE
+// division / sqrt, the RNG and the texture filter, one element per thread, so that
+// tests/test_gpu_device_units.py can compare them bit for bit with the host compile of the same
+// headers (the oracle) -- including the edge values whole-image parity tests almost never reach
+// (rand() == 0 -> log(0), rand() == 1, trig sign bits at exact zeros, subnormals, inf, NaN).
+// fn: 0 log, 1 cos, 2 sin, 3 exp, 4 exp2, 5 log2, 6 pow(x, y), 7 acos, 8 atan2(x, y), 9 sqrt, 10 x / y
+// (the oracle's numbering), 11 rand() of RNG state bits x -> float, 12 the generator's u32 output for
+// state x, 13 trig_signbits(x), 14 rand_normal_dist() of state x, 15 f32(u32 x) * 2^-32 (rand()'s
+// conversion for a raw generator output), 16 normalize(x, y, x*y).x (division by a sqrt)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rt_units_kernel(int fn, const float* __restrict__ x, const float* __restrict__ y,
+                                                       float* __restrict__ out, unsigned long long n) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float a = x[i], b = y[i];
+    float r = 0.0f;
+    switch (fn) {
+        case 0: r = rtm::log_(a); break;
+        case 1: r = rtm::cos_(a); break;
+        case 2: r = rtm::sin_(a); break;
+        case 3: r = rtm::exp_(a); break;
+        case 4: r = rtm::exp2_(a); break;
+        case 5: r = rtm::log2_(a); break;
+        case 6: r = rtm::pow_(a, b); break;
+        case 7: r = rtm::acos_(a); break;
+        case 8: r = rtm::atan2_(a, b); break;
+        case 9: r = rtm::sqrt_(a); break;
+        case 10: r = a / b; break;
+        case 11: { uint32_t s = __float_as_uint(a); r = rand_(s); break; }
+        case 12: { uint32_t s = __float_as_uint(a); r = __uint_as_float(next_random_number(s)); break; }
+        case 13: r = __uint_as_float(rtm::trig_signbits(a)); break;
+        case 14: { uint32_t s = __float_as_uint(a); r = rand_normal_dist(s); break; }
+        case 15: r = (float)__float_as_uint(a) * 0x1p-32f; break;
+        case 16: r = normalize3(f3{a, b, a * b}).x; break;
+        default: break;
+    }
+    out[i] = r;
+}
+
+__global__ void __launch_bounds__(256) rt_units_texture_kernel(const uint8_t* rgba8, uint32_t width, uint32_t height,
+                                                               const float* srgb_lut, const float* __restrict__ uv,
+                                                               float* __restrict__ out, unsigned long long n) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    typedef const __attribute__((address_space(1))) uint32_t* GWords;
+    typedef const __attribute__((address_space(1))) float* GFloats;
+    float o[4];
+    rtm::sample_bilinear_words((GWords)(const void*)rgba8, width, height, (GFloats)(const void*)srgb_lut, uv[2 * i], uv[2 * i + 1], o);
+    out[4 * i] = o[0]; out[4 * i + 1] = o[1]; out[4 * i + 2] = o[2]; out[4 * i + 3] = o[3];
+}
+
+hipError_t launch_units(int fn, const float* x, const float* y, float* out, unsigned long long n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_units_kernel, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, stream, fn, x, y, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_units_texture(const uint8_t* rgba8, uint32_t width, uint32_t height, const float* srgb_lut, const float* uv,
+                                float* out, unsigned long long n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_units_texture_kernel, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, stream, rgba8, width, height,
+                       srgb_lut, uv, out, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_primary(const RenderArgs& a, float* table, hipStream_t stream) {
     if (a.params.width == 0 || a.params.height == 0) return hipSuccess;
     hipLaunchKernelGGL(rt_primary_kernel, dim3((a.params.width + 63u) / 64u, (a.params.height + 3u) / 4u), dim3(256), 0, stream, a, table);

@@ -121,6 +121,22 @@ class RayTracer:
     def bind_image(self, device_ptr, texels):
         self._check(self._L.rt_bind_image(self._h, device_ptr, texels))
 
+    # ---- test-only: the device's arithmetic building blocks (tests/test_gpu_device_units.py) ----
+    def device_units(self, fn, x, y=None):
+        x = np.ascontiguousarray(x).view(np.float32).ravel()
+        y = np.zeros_like(x) if y is None else np.ascontiguousarray(y).view(np.float32).ravel()
+        out = np.empty_like(x)
+        self._check(self._L.rt_test_device_units(self._h, fn, x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size))
+        return out
+
+    def device_sample_texture(self, tex_rgba8, uv):
+        tex = np.ascontiguousarray(tex_rgba8, dtype=np.uint8)
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        d = A.TextureDesc(tex.ctypes.data, tex.shape[1], tex.shape[0])
+        out = np.empty((uv.shape[0], 4), np.float32)
+        self._check(self._L.rt_test_device_sample_texture(self._h, C.byref(d), uv.ctypes.data, out.ctypes.data, uv.shape[0]))
+        return out
+
     def stats(self):
         s = A.Stats()
         self._check(self._L.rt_get_stats(self._h, C.byref(s)))

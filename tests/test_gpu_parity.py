@@ -101,3 +101,16 @@ def test_counters_match_oracle(rt, oracle, loaded, cornell):
         loaded.set_counters(False)
     _, st = oracle.render(p, cornell)
     assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests)
+
+
+def test_export_of_a_rendered_frame(rt, oracle, loaded, cornell):
+    """SURVEY 8(f)-3 on the device's output: rt_read_image + rt_export_rgba8 (app.rs:341-460) against the
+    oracle's frame through the oracle's restatement of the export loop."""
+    w, h = 96, 54
+    p = rt.make_params(w, h, 4, 4, skybox=1, frames=0)
+    loaded.render(p)
+    gpu = loaded.read_image(w, h)
+    out = np.zeros((h, w, 4), np.uint8)
+    assert rt.load().rt_export_rgba8(gpu.ctypes.data, w, h, out.ctypes.data) == 0
+    ref, _ = oracle.render(p, cornell)
+    assert np.array_equal(out, oracle.export_rgba8(ref))

@@ -529,3 +529,21 @@ def test_gpu_sah_search_builds_the_same_bvh(rt, case):
 
     ref = built()
     assert built(device=0, min_triangles=1) == ref
+    if case == "dragon_x9":
+        return
+    # ... and against the independent restatement of bvh.rs:208-470 (oracle/host_oracle.py), mesh by mesh:
+    # the device build is still loaded in `sc`
+    from oracle import host_oracle as ho
+    a = rt.SceneArrays.from_scene(sc)
+    raw = sc.raw_meshes()
+    assert len(raw) == a.meshes.shape[0]
+    for i, (_label, v, idx, _t, _m) in enumerate(raw):
+        P = np.ascontiguousarray(v[:, :3], np.float32)[np.asarray(idx).reshape(-1)].reshape(-1, 3, 3)
+        order, nodes = ho.build_bvh(P)
+        t0, n0 = int(a.meshes["triangle_offset"][i]), int(a.meshes["node_offset"][i])
+        tri, nd = a.triangles[t0:t0 + len(order)], a.nodes[n0:n0 + len(nodes)]
+        assert np.array_equal(bits(tri["v1"]), bits(P[order, 0])) and np.array_equal(bits(tri["v2"]), bits(P[order, 1]))
+        assert nd["left"].tolist() == [x["left"] for x in nodes] and nd["right"].tolist() == [x["right"] for x in nodes]
+        assert nd["first"].tolist() == [x["first"] for x in nodes] and nd["count"].tolist() == [x["count"] for x in nodes]
+        assert np.array_equal(bits(nd["aabb_min"]), bits(np.array([x["mn"] for x in nodes], np.float32)))
+        assert np.array_equal(bits(nd["aabb_max"]), bits(np.array([x["mx"] for x in nodes], np.float32)))

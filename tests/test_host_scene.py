@@ -104,7 +104,7 @@ def test_loader_against_python_oracle(rt):
         assert np.array_equal(bits(nd["aabb_max"]), bits(np.array([n["mx"] for n in nodes], np.float32)))
 
 
-@pytest.mark.parametrize("seed,n", [(1, 1), (2, 2), (3, 7), (4, 40), (5, 200)])
+@pytest.mark.parametrize("seed,n", [(1, 1), (2, 2), (3, 7), (4, 40), (5, 200), (6, 300)])
 def test_bvh_builder_against_python_oracle_on_random_soups(rt, seed, n):
     from oracle import host_oracle as ho
     rng = np.random.RandomState(seed)
@@ -112,6 +112,8 @@ def test_bvh_builder_against_python_oracle_on_random_soups(rt, seed, n):
     P = (centre + rng.uniform(-0.4, 0.4, (n, 3, 3))).astype(np.float32)
     if seed == 4:
         P[:, :, 1] = 0.25   # flat soup: one zero-extent axis is skipped (bvh.rs:329-331)
+    if seed == 6:
+        P = np.round(P, 1)  # coordinates on a grid: equal centroids, zeros of both signs (f32::min keeps self)
     v8 = np.zeros((n * 3, 8), np.float32)
     v8[:, :3] = P.reshape(-1, 3)
     v8[:, 3:6] = [0, 1, 0]
@@ -125,6 +127,7 @@ def test_bvh_builder_against_python_oracle_on_random_soups(rt, seed, n):
     assert nd["left"].tolist() == [x["left"] for x in nodes] and nd["right"].tolist() == [x["right"] for x in nodes]
     assert nd["first"].tolist() == [x["first"] for x in nodes] and nd["count"].tolist() == [x["count"] for x in nodes]
     assert np.array_equal(bits(nd["aabb_min"]), bits(np.array([x["mn"] for x in nodes], np.float32)))
+    assert np.array_equal(bits(nd["aabb_max"]), bits(np.array([x["mx"] for x in nodes], np.float32)))
     # structural invariants: leaves partition the triangles, children boxes inside the parent
     leaves = nd[nd["count"] > 0]
     assert sorted(sum([list(range(f, f + c)) for f, c in zip(leaves["first"], leaves["count"])], [])) == list(range(n))
@@ -182,6 +185,32 @@ def test_builtin_scene_library(rt):
         rt.Scene.from_name("no_such_scene", DATA)
     with pytest.raises(rt.RtError):
         rt.Scene.from_name("room_2", DATA)   # Dragon_80K.obj is absent: clean error, no abort
+
+
+def test_export_rgba8_against_the_oracle_restatement(rt, oracle):
+    """rt_export_rgba8 == the literal restatement of app.rs:408-460 (reversed x loop + two flips) on a full
+    golden frame and on the values the cast rules decide: NaN, +-inf, negatives, > 1, subnormals, values whose
+    scaled result sits next to an integer.  Both sides call the platform's powf, as Rust's f32::powf does."""
+    gold = np.load(os.path.join(GOLDEN, "cornell_golden.npz"))
+    frames = [gold["frame_256_sky1"], gold["frame_256_sky0"]]
+    rng = np.random.RandomState(9)
+    odd = rng.uniform(-0.5, 1.5, (37, 53, 4)).astype(np.float32)   # odd sizes: the flips' middle row / column
+    odd.reshape(-1)[:16] = [np.nan, np.inf, -np.inf, -0.0, 0.0, 1.0, 1e-45, -1e-45, 2.0, 0.99999994, 1.0000001, 0.5, 0.21404114, 1e30, -1.0, 3e-39]
+    k = np.arange(256, dtype=np.float64)
+    edges = ((k / 255.0) ** 2.2).astype(np.float32)                  # pow(v, 1/2.2) * 255 lands near the integer k
+    edge_img = np.stack([np.nextafter(edges, np.float32(-1)), edges, np.nextafter(edges, np.float32(2)), edges], axis=1).reshape(16, 16, 4)
+    L = rt.load()
+    for img in frames + [odd, edge_img, np.zeros((1, 1, 4), np.float32), np.ones((2, 1, 4), np.float32)]:
+        h, w = img.shape[:2]
+        img = np.ascontiguousarray(img, np.float32)
+        out = np.zeros((h, w, 4), np.uint8)
+        assert L.rt_export_rgba8(img.ctypes.data, w, h, out.ctypes.data) == 0
+        ref = oracle.export_rgba8(img)
+        assert np.array_equal(out, ref)
+        # independent of libm up to the truncation boundary: within one step of the double-precision formula
+        with np.errstate(all="ignore"):
+            d = np.clip(np.nan_to_num(np.power(img[::-1].astype(np.float64), 1 / 2.2), nan=0.0), 0, 1) * 255
+        assert np.all(np.abs(out.astype(np.float64) - np.floor(d)) <= 1)
 
 
 def test_export_rgba8_matches_save_render_to_file(rt):

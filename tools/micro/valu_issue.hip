@@ -17,7 +17,9 @@
 #define OPS_IN , "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
 
 template <int KIND>
-__global__ void __launch_bounds__(256, 8) k(float* out, int iters, float seed, unsigned long long* cyc, unsigned* hwid) {
+__global__ void __launch_bounds__(256, 8) k(float* out, int iters, float seed, unsigned long long* cyc, unsigned* hwid,
+                                            unsigned long long* rt) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
     float a[16];
     for (int i = 0; i < 16; ++i) a[i] = seed + threadIdx.x + i;
     float b = seed * 0.5f + 1.0f;
@@ -60,6 +62,8 @@ __global__ void __launch_bounds__(256, 8) k(float* out, int iters, float seed, u
     const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     if ((threadIdx.x & 63) == 0) {
         cyc[wave] = t1 - t0;
+        rt[2 * wave] = r0;
+        rt[2 * wave + 1] = __builtin_amdgcn_s_memrealtime();
         unsigned id;
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
@@ -79,18 +83,20 @@ void run(const char* name) {
     float* out;
     unsigned long long* cyc;
     unsigned* hwid;
+    unsigned long long* rt;
+    hipMalloc(&rt, (size_t)cus * 8 * 4 * 16);
     hipMalloc(&out, (size_t)cus * 8 * 256 * 4);
     hipMalloc(&cyc, (size_t)cus * 8 * 4 * 8);
     hipMalloc(&hwid, (size_t)cus * 8 * 4 * 4);
     for (int wps : {1, 2, 4, 5, 8}) {
         const int blocks = cus * wps, waves = blocks * 4;
-        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 200, 1.0f, cyc, hwid);
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 200, 1.0f, cyc, hwid, rt);
         hipDeviceSynchronize();
         hipEvent_t e0, e1;
         hipEventCreate(&e0);
         hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f, cyc, hwid);
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f, cyc, hwid, rt);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -99,6 +105,20 @@ void run(const char* name) {
         std::vector<unsigned> hid(waves);
         hipMemcpy(hc.data(), cyc, waves * 8, hipMemcpyDeviceToHost);
         hipMemcpy(hid.data(), hwid, waves * 4, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> hr(2 * waves);
+        hipMemcpy(hr.data(), rt, waves * 16, hipMemcpyDeviceToHost);
+        // concurrency: summed wave lifetimes over the span from the first start to the last end (100 MHz ticks),
+        // per SIMD = waves that were resident together on average; shader clock = s_memtime ticks per real time
+        unsigned long long first = ~0ull, last = 0;
+        double life = 0, clock = 0;
+        for (int w = 0; w < waves; ++w) {
+            first = hr[2 * w] < first ? hr[2 * w] : first;
+            last = hr[2 * w + 1] > last ? hr[2 * w + 1] : last;
+            life += (double)(hr[2 * w + 1] - hr[2 * w]);
+            clock += (double)hc[w] / ((double)(hr[2 * w + 1] - hr[2 * w]) * 10e-9) / 1e9;
+        }
+        const double together = life / (double)(last - first) / (cus * 4);
+        clock /= waves;
         double avg = 0, mx = 0;
         std::map<unsigned, int> per_simd;  // (xcc | se | sh | cu | simd) -> resident waves of this launch
         for (int w = 0; w < waves; ++w) {
@@ -110,9 +130,12 @@ void run(const char* name) {
         int lo = 1 << 30, hi = 0;
         for (auto& kv : per_simd) { lo = kv.second < lo ? kv.second : lo; hi = kv.second > hi ? kv.second : hi; }
         const double n = (double)iters * 16 * wps;  // wave-instructions per SIMD if every SIMD holds wps waves
-        printf("%-14s waves/SIMD %d: %5.2f cycles per wave64 instruction per SIMD (mean wave), %5.2f (slowest wave); wall %.3f ms "
-               "=> %.2f GHz; placement: %zu SIMD ids, %d..%d waves each\n", name, wps, avg / n, mx / n, ms, avg / (ms * 1e-3) / 1e9,
-               per_simd.size(), lo, hi);
+        (void)mx;
+        // SIMD rate from real time: instructions of one SIMD / (span x measured clock)
+        const double span_s = (double)(last - first) * 10e-9;
+        printf("%-14s waves/SIMD %d: %5.2f shader cycles per wave64 instruction per SIMD (span %.3f ms x %.2f GHz measured clock / %.0f "
+               "instructions); one wave sees %5.2f cycles per instruction; %.2f waves per SIMD resident together; placement %zu SIMDs, %d..%d waves each\n",
+               name, wps, span_s * clock * 1e9 / n, span_s * 1e3, clock, n, avg / ((double)iters * 16), together, per_simd.size(), lo, hi);
     }
     hipFree(out);
     hipFree(cyc);
