@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--algorithmic-bytes-per-frame", type=float, default=1920 * 1080 * 32 + 6528)
     ap.add_argument("--frames-per-launch", type=int, default=16)
     ap.add_argument("--note", default="")
+    ap.add_argument("--demand-json", default="", help="tools/bench_scene.py BS_JSON output: demand bytes per segment from the stats counters")
     ap.add_argument("--no-latest", action="store_true", help="do not rewrite profiles/latest_traffic.json (not the headline config)")
     args = ap.parse_args()
     d = args.dir
@@ -125,6 +126,24 @@ def main():
             rate = agg["SQ_INSTS_VALU"] / dur(steady) / 1e9
             lines.append(f"VALU issue: {rate:.0f} G wave-instructions/s = {rate / (simds * clk / 2):.2f} of the guide's peak "
                          f"(one wave64 instruction per 2 cycles per SIMD x {simds} SIMDs x {clk:.2f} GHz = {simds * clk / 2:.0f} G/s)")
+    if args.demand_json and os.path.exists(args.demand_json):
+        dj = json.load(open(args.demand_json))
+        lines.append("")
+        lines.append(f"== demand vs counter bytes ({dj['scene']}, {dj['width']}x{dj['height']}, {dj['spp']} spp, {dj['bounces']} bounces) ==")
+        lines.append(f"scene: {dj['triangles']} triangles, {dj['nodes']} nodes, {dj['meshes']} meshes = {dj.get('scene_bytes_reference_layout', 0) / 1e6:.1f} MB in the reference's layout")
+        lines.append(f"un-profiled run: {dj['ms_per_frame']:.3f} ms/frame, {dj['rays_per_frame'] / 1e6:.2f} M rays/frame ({dj['rays_traversed_per_frame'] / 1e6:.2f} M traversed), {dj['mrays_per_s']:.0f} Mrays/s")
+        if "demand_bytes_per_segment" in dj:
+            lines.append(f"stats counters (wgsl:307,322): {dj['node_tests_per_segment']:.1f} box tests + {dj['triangle_tests_per_segment']:.1f} triangle tests per segment "
+                         f"-> demand = box tests x 48 + triangle tests x 96 + meshes x 240 = {dj['demand_bytes_per_segment']:.0f} B per segment = "
+                         f"{dj['demand_bytes_per_frame'] / 1e9:.2f} GB per frame")
+            if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
+                per_frame = (agg["FETCH_SIZE"] * 2048 + agg["WRITE_SIZE"] * 1024 + agg_blend.get("FETCH_SIZE", 0) * 2048 + agg_blend.get("WRITE_SIZE", 0) * 1024) / args.frames_per_launch
+                lines.append(f"counter bytes (HBM): {per_frame / 1e6:.1f} MB per frame = {per_frame / dj['demand_bytes_per_frame']:.4f} of the demand bytes "
+                             f"(the rest is served by LDS / L1 / L2); compulsory = image {dj['width'] * dj['height'] * 32 / 1e6:.1f} MB + scene once "
+                             f"{dj.get('scene_bytes_reference_layout', 0) / 1e6:.1f} MB")
+                lines.append(f"HBM roofline: {per_frame / (dj['kernel_ms_per_frame'] * 1e-3) / 1e9:.0f} GB/s of counter traffic = "
+                             f"{per_frame / (dj['kernel_ms_per_frame'] * 1e-3) / 8e12:.4f} of the 8 TB/s peak; demand rate "
+                             f"{dj['demand_bytes_per_frame'] / (dj['kernel_ms_per_frame'] * 1e-3) / 1e12:.2f} TB/s")
     if rec is not None and not args.no_latest:
         json.dump(rec, open(os.path.join(HERE, "latest_traffic.json"), "w"))
     out = os.path.join(HERE, f"{tag}_summary.txt")

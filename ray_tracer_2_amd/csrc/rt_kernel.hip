@@ -206,6 +206,28 @@ DEV int ldi(const RenderArgs& a, uint32_t byte_off) {
 }
 DEV uint32_t fbits(float f) { return __float_as_uint(f); }
 
+// float4 offset of the LDS-staged BVH top (global-memory kernels): behind the wave regions and cost tables
+DEV uint32_t top_lds_off16(const RenderArgs& a);
+
+// The wide record `idx` (absolute index): from the staged scene, from the LDS-staged top of the big
+// mesh's BVH, or from global memory.
+template <bool LDS>
+DEV void load_wide(const RenderArgs& a, uint32_t idx, float4& q0, float4& q1, float4& q2, float4& q3) {
+    if constexpr (LDS) {
+        const uint32_t wo = a.lay.wide_off + idx * WIDE_REC_BYTES;
+        q0 = ld4<true>(a, wo); q1 = ld4<true>(a, wo + 16); q2 = ld4<true>(a, wo + 32); q3 = ld4<true>(a, wo + 48);
+    } else {
+        const uint32_t rel = idx - a.top_base;
+        if (rel < a.top_count) {
+            const float4* p = lds_mem + top_lds_off16(a) + rel * 4u;
+            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+        } else {
+            const uint32_t wo = a.lay.wide_off + idx * WIDE_REC_BYTES;
+            q0 = ld4<false>(a, wo); q1 = ld4<false>(a, wo + 16); q2 = ld4<false>(a, wo + 32); q3 = ld4<false>(a, wo + 48);
+        }
+    }
+}
+
 // (mat4 * vec4(v, w)).xyz with the four columns as float4
 DEV f3 mat_cols_xyz(float4 c0, float4 c1, float4 c2, float4 c3, f3 v, float w) {
     f3 r;
@@ -325,7 +347,6 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
         return;
     }
     TIC(t16);
-    const uint32_t wide0 = a.lay.wide_off;
     if (deep) {
         // BVH of height >= 32: the shader's `array<u32,32>` stack can overflow, and what it
         // then does is defined by naga's Restrict policy (out-of-range indices are clamped to
@@ -345,9 +366,8 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
                     tri_test<8>(lo, ld, ld4<LDS>(a, t), ld4<LDS>(a, t + 16), ld4<LDS>(a, t + 32), cull, idx + j, best);
                 }
             } else {
-                const uint32_t wo = wide0 + idx * WIDE_REC_BYTES;
-                const float4 q0 = ld4<LDS>(a, wo), q1 = ld4<LDS>(a, wo + 16), q2 = ld4<LDS>(a, wo + 32),
-                             q3 = ld4<LDS>(a, wo + 48);
+                float4 q0, q1, q2, q3;
+                load_wide<LDS>(a, idx, q0, q1, q2, q3);
                 float da = aabb_dist(lo, inv, q0, q1, best.t);
                 float db = aabb_dist(lo, inv, q2, q3, best.t);
                 if (STATS) node_tests += 2;
@@ -370,9 +390,8 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
         bool finished = false;
         while (cur_count == 0) {
             DIAG(7);
-            const uint32_t wo = wide0 + cur * WIDE_REC_BYTES;
-            const float4 q0 = ld4<LDS>(a, wo), q1 = ld4<LDS>(a, wo + 16), q2 = ld4<LDS>(a, wo + 32),
-                         q3 = ld4<LDS>(a, wo + 48);
+            float4 q0, q1, q2, q3;
+            load_wide<LDS>(a, cur, q0, q1, q2, q3);
             float da = aabb_dist(lo, inv, q0, q1, best.t);
             float db = aabb_dist(lo, inv, q2, q3, best.t);
             if (STATS) node_tests += 2;
@@ -436,7 +455,7 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
         else if (STATS) node_tests += 2;  // the shader's two root-level tests (wgsl:322)
     }
     TOC(t5, 5);
-    const uint32_t tri0 = a.lay.tri_off, wide0 = a.lay.wide_off;
+    const uint32_t tri0 = a.lay.tri_off;
     const LaneStack st{stack, a.stack_wide != 0u};
     uint32_t cur = 0, cur_count = 0, sp = 0, mesh = 0;
     bool have = false, cull = false;
@@ -469,9 +488,8 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
         TIC(t6);
         while (have && cur_count == 0) {  // descend to the next leaf
             DIAG(7);
-            const uint32_t wo = wide0 + cur * WIDE_REC_BYTES;
-            const float4 q0 = ld4<LDS>(a, wo), q1 = ld4<LDS>(a, wo + 16), q2 = ld4<LDS>(a, wo + 32),
-                         q3 = ld4<LDS>(a, wo + 48);
+            float4 q0, q1, q2, q3;
+            load_wide<LDS>(a, cur, q0, q1, q2, q3);
             float da = aabb_dist(lo, inv, q0, q1, b.t);
             float db = aabb_dist(lo, inv, q2, q3, b.t);
             if (STATS) node_tests += 2;
@@ -859,6 +877,8 @@ DEV uint32_t wave_region_dwords(const RenderArgs& a) {
            stack_dwords(a) + a.tlas_entries * 64u;
 }
 
+DEV uint32_t top_lds_off16(const RenderArgs& a) { return (WAVES_PER_BLOCK * wave_region_dwords(a) + WAVES_PER_BLOCK * 8u * 3u) >> 2; }
+
 // Stage the scene blob into LDS (coalesced 16-byte loads, whole workgroup) and
 // return this lane's base pointer (its lane state; see the map above).
 template <bool LDS>
@@ -869,6 +889,11 @@ DEV uint32_t* block_prologue(const RenderArgs& a) {
         for (uint32_t i = threadIdx.x; i < n16; i += BLOCK_THREADS) lds_mem[i] = a.blob[i];
         __syncthreads();
         base = n16;
+    } else if (a.top_count != 0u) {
+        // the top of the big mesh's BVH: top_count consecutive wide records
+        const uint32_t src = (a.lay.wide_off + a.top_base * WIDE_REC_BYTES) >> 4, dst = top_lds_off16(a);
+        for (uint32_t i = threadIdx.x; i < a.top_count * 4u; i += BLOCK_THREADS) lds_mem[dst + i] = a.blob[src + i];
+        __syncthreads();
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     return reinterpret_cast<uint32_t*>(lds_mem + base) + wave * wave_region_dwords(a) +
@@ -1060,6 +1085,28 @@ enum : uint32_t {
     STEP_TRAVERSE = 3,  // intersect the scene
 };
 
+// Walk vote heuristic: may the ray (ro, rd) enter one of the launch's walk boxes?  Slab test with an
+// approximate reciprocal (v_rcp_f32): scheduling only, see RenderArgs::walk_box.
+DEV bool may_enter_walk_boxes(const RenderArgs& a, f3 ro, f3 rd) {
+    const f3 inv{__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z)};
+    auto hits = [&](uint32_t k0, uint32_t k1) {
+        bool any = false;
+        for (uint32_t k = k0; k < k1; ++k) {
+            const float* b = a.walk_box[k];
+            const float t1x = (b[0] - ro.x) * inv.x, t2x = (b[3] - ro.x) * inv.x;
+            const float t1y = (b[1] - ro.y) * inv.y, t2y = (b[4] - ro.y) * inv.y;
+            const float t1z = (b[2] - ro.z) * inv.z, t2z = (b[5] - ro.z) * inv.z;
+            const float t_near = max_(max_(min_(t1x, t2x), min_(t1y, t2y)), min_(t1z, t2z));
+            const float t_far = min_(min_(max_(t1x, t2x), max_(t1y, t2y)), max_(t1z, t2z));
+            any = any || (t_far >= t_near && t_far > 0.0f);
+        }
+        return any;
+    };
+    bool any = hits(0u, a.walk_coarse);
+    if (a.walk_coarse < a.walk_boxes && any) any = hits(a.walk_coarse, a.walk_boxes);
+    return any;
+}
+
 template <bool STATS>
 DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve) {
     const int32_t nb = a.params.number_of_bounces;
@@ -1114,12 +1161,24 @@ DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32
     // it (or somebody has already waited); the waiting lanes simply take their turn in the
     // next iteration, by which time the memoised-primary lanes have moved on to secondary
     // segments and want it too.  Pure scheduling: no lane's sequence of operations changes.
+    // (`starve` holds both votes' wait counts: bits 0-15 this one, bits 16-31 the walk vote)
     if (cache_on) {
         const uint32_t n_here = (uint32_t)__popcll(__ballot(true));
         const uint32_t n_want = (uint32_t)__popcll(__ballot(!reuse_hit));
-        const bool run = n_want * 8u >= n_here * a.vote_eighths || starve >= a.vote_patience;
-        starve = (n_want != 0u && !run) ? starve + 1u : 0u;
+        const bool run = n_want * 8u >= n_here * a.vote_eighths || (starve & 0xffffu) >= a.vote_patience;
+        starve = (n_want != 0u && !run) ? starve + 1u : (starve & 0xffff0000u);
         if (!reuse_hit && !run) return STEP_WAIT;  // nothing about this lane has changed
+    }
+    // Walk vote.  The long, sparsely entered walks (RenderArgs::walk_box) cost the wave their full length
+    // whenever a single lane takes one; a lane whose ray may take one waits -- with its path state
+    // untouched, it has not started the segment -- until enough lanes of the wave want the same.
+    if (a.walk_boxes != 0u) {
+        const bool wants_walk = !reuse_hit && may_enter_walk_boxes(a, s.ro, s.rd);
+        const uint32_t n_here = (uint32_t)__popcll(__ballot(true));
+        const uint32_t n_walk = (uint32_t)__popcll(__ballot(wants_walk));
+        const bool run = n_walk * 8u >= n_here * a.walk_eighths || (starve >> 16) >= a.walk_patience;
+        starve = (n_walk != 0u && !run) ? starve + 0x10000u : (starve & 0xffffu);
+        if (wants_walk && !run) return STEP_WAIT;
     }
     return reuse_hit ? STEP_REUSE : STEP_TRAVERSE;
 }
@@ -1694,7 +1753,7 @@ size_t render_lds_bytes(const RenderArgs& a) {
     size_t lane_state = (a.lds_scene && RT_TOTAL_IN_LDS) ? (size_t)LANE_STATE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
     size_t cache = a.pixel_cache == 1u ? (size_t)PIXEL_MEMO_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
     // (= 4 x wave_region_dwords + the cost tables, see the LDS map)
-    return stacks + cost_tables + lane_state + cache + (a.lds_scene ? a.lay.bytes : 0u);
+    return stacks + cost_tables + lane_state + cache + (a.lds_scene ? a.lay.bytes : (size_t)a.top_count * WIDE_REC_BYTES);
 }
 
 // Dynamic LDS above 64 KiB (deep-BVH stacks) has to be opted into per kernel.

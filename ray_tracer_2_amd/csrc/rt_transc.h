@@ -220,7 +220,10 @@ RT_HD float cos_kernel(float x) {
 }
 
 // x = n*(pi/2) + r, |r| <= ~pi/4.  Three-term Cody-Waite with fma; accurate
-// for |x| < ~1e5 (the shader only passes angles in [0, 2*pi]).
+// for |x| < ~1e5 (the shader only passes angles in [0, 2*pi]).  Callers keep |x| < 2^31 so that the
+// float -> int conversion of n is defined (it saturates on gfx950 and yields INT_MIN on x86: found by
+// tests/test_gpu_device_units.py); beyond that, and for inf / NaN, sin_ and cos_ return the canonical
+// quiet NaN 0x7fc00000 on both sides (an invalid operation's NaN would be negative on x86, positive on gfx950).
 struct TrigRed {
     float r;
     int q;
@@ -243,7 +246,7 @@ RT_HD TrigRed trig_reduce(float x) {
 
 RT_HD float sin_(float x) {
     uint32_t ax = f2u(x) & 0x7fffffffu;
-    if (ax >= 0x7f800000u) return x - x;  // inf/NaN -> NaN
+    if (ax >= 0x4f000000u) return u2f(0x7fc00000u);  // |x| >= 2^31, inf, NaN -> NaN
     if (ax < 0x3f490fdau) return sin_kernel(x);  // |x| < pi/4
     TrigRed t = trig_reduce(x);
     float s = sin_kernel(t.r), c = cos_kernel(t.r);
@@ -253,7 +256,7 @@ RT_HD float sin_(float x) {
 
 RT_HD float cos_(float x) {
     uint32_t ax = f2u(x) & 0x7fffffffu;
-    if (ax >= 0x7f800000u) return x - x;
+    if (ax >= 0x4f000000u) return u2f(0x7fc00000u);
     if (ax < 0x3f490fdau) return cos_kernel(x);
     TrigRed t = trig_reduce(x);
     float s = sin_kernel(t.r), c = cos_kernel(t.r);
@@ -269,6 +272,7 @@ RT_HD float cos_(float x) {
 RT_HD uint32_t trig_signbits(float x) {  // bit 0: cos_(x) negative, bit 1: sin_(x) negative
     uint32_t ax = f2u(x) & 0x7fffffffu;
     if (ax < 0x3f490fdau) return x < 0.0f ? 2u : 0u;
+    if (ax >= 0x4f000000u) return 0u;  // sin_ / cos_ return the positive canonical NaN there
     TrigRed t = trig_reduce(x);
     const uint32_t s_neg = t.r < 0.0f ? 1u : 0u;
     const uint32_t q = (uint32_t)t.q;

@@ -6,7 +6,6 @@ Builds ray_tracer_2_amd/librt2_mi355x_diag.so on first use (hipcc).
 """
 import ctypes as C
 import os
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,21 +29,11 @@ TIMED = {0: "intersect_scene (all)", 1: "sample start (ray gen / memo ray)", 2: 
 
 
 def build_timed():
-    srcs = [os.path.join(build.CSRC, s) for s in build.PRODUCT_SOURCES]
-    if os.path.exists(TIME_SO) and all(os.path.getmtime(TIME_SO) > os.path.getmtime(s) for s in srcs):
-        return
-    subprocess.run([build.hipcc_path(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
-                    "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared", "-DRT_DIAGT=1", "-I", os.path.join(ROOT, "include"),
-                    *srcs, "-lz", "-o", TIME_SO], check=True)
+    build.build_product(extra_flags=("-DRT_DIAGT=1",), out=TIME_SO)
 
 
 def build_diag():
-    srcs = [os.path.join(build.CSRC, s) for s in build.PRODUCT_SOURCES]
-    if os.path.exists(DIAG_SO) and all(os.path.getmtime(DIAG_SO) > os.path.getmtime(s) for s in srcs):
-        return
-    subprocess.run([build.hipcc_path(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off",
-                    "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared", "-DRT_DIAG=1", "-I", os.path.join(ROOT, "include"),
-                    *srcs, "-lz", "-o", DIAG_SO], check=True)
+    build.build_product(extra_flags=("-DRT_DIAG=1",), out=DIAG_SO)
 
 
 def main():
