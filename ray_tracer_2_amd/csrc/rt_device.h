@@ -101,11 +101,21 @@ constexpr uint32_t WAVES_PER_BLOCK = BLOCK_THREADS / 64;
 #define RT_TOTAL_IN_LDS 1   // 0 (experiment): the pixel sum stays in registers in every kernel
 #endif
 constexpr uint32_t LANE_STATE_DWORDS = RT_TOTAL_IN_LDS ? 4 : 0;
+// The same in the kernels that read the scene from global memory: held in registers the sum was spilled
+// around the traversal in every iteration (6 scratch stores + 6 loads per wave-iteration = 1.2 GB of writes
+// per frame on the config 3 stand-in, profiles/r02_dragon9_summary.txt); 4 KiB of LDS per workgroup.
+#ifndef RT_TOTAL_LDS_GLOBAL
+#define RT_TOTAL_LDS_GLOBAL 1
+#endif
+constexpr bool total_in_lds(bool lds_scene) { return RT_TOTAL_IN_LDS != 0 && (lds_scene || RT_TOTAL_LDS_GLOBAL != 0); }
 // Per-lane primary-ray memo (see path_step): rd, hit record (dst, point, normal, u, v), and
 // one word = mat_off | hit | backface << 1 | ray valid << 2 | hit valid << 3.
 constexpr uint32_t PIXEL_MEMO_DWORDS = 13;
 
 constexpr uint32_t RT_WALK_BOXES = 12;
+#ifndef RT_WALK_VOTE
+#define RT_WALK_VOTE 1   // 0: compile the walk vote out of the render kernels (A/B of its register cost)
+#endif
 
 struct DTexture {
     const uint8_t* rgba8;

@@ -869,9 +869,7 @@ DEV void store_texel(const A& a, uint32_t x, uint32_t out_row, uint32_t batch_fr
 //   [lane state, LANE_STATE_DWORDS x 64] [BVH stack, stack_entries x 2 x 64] [TLAS stack, tlas_entries x 64]
 // Everything is addressed from ONE per-lane pointer (the lane-state base) with immediate
 // offsets, so the whole map costs a single VGPR.
-// (kernels that read the scene from global memory tend to have deep stacks and an LDS-bound
-// occupancy: they keep the pixel sum in registers instead)
-DEV uint32_t lane_state_dwords(const RenderArgs& a) { return (a.lds_scene && RT_TOTAL_IN_LDS) ? LANE_STATE_DWORDS : 0u; }
+DEV uint32_t lane_state_dwords(const RenderArgs& a) { return total_in_lds(a.lds_scene != 0u) ? LANE_STATE_DWORDS : 0u; }
 DEV uint32_t wave_region_dwords(const RenderArgs& a) {
     return (a.pixel_cache == 1u ? PIXEL_MEMO_DWORDS * 64u : 0u) + lane_state_dwords(a) * 64u +
            stack_dwords(a) + a.tlas_entries * 64u;
@@ -900,7 +898,7 @@ DEV uint32_t* block_prologue(const RenderArgs& a) {
            (a.pixel_cache == 1u ? PIXEL_MEMO_DWORDS * 64u : 0u) + lane;
 }
 template <bool LDS>
-DEV uint32_t* stack_of(uint32_t* lane_base) { return lane_base + (LDS ? LANE_STATE_DWORDS * 64u : 0u); }
+DEV uint32_t* stack_of(uint32_t* lane_base) { return lane_base + (LDS ? LANE_STATE_DWORDS * 64u : 0u); }  // LDS = total_in_lds(...)
 
 // The persistent kernel's per-wave tile-cost tables follow the wave regions.
 template <bool LDS>
@@ -938,7 +936,7 @@ struct PixelState {
     uint32_t rng;          // wgsl:475, one stream per pixel
     int32_t j;             // sample index (wgsl:487)
     // current path (wgsl:398-471); `total` (wgsl:486) lives in the lane's LDS state region
-    // (LANE_STATE_DWORDS) in the LDS-scene kernels, in registers otherwise
+    // (LANE_STATE_DWORDS)
     f4 total;
     f3 ro, rd;
     f4 T, light;
@@ -1172,6 +1170,7 @@ DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32
     // Walk vote.  The long, sparsely entered walks (RenderArgs::walk_box) cost the wave their full length
     // whenever a single lane takes one; a lane whose ray may take one waits -- with its path state
     // untouched, it has not started the segment -- until enough lanes of the wave want the same.
+#if RT_WALK_VOTE
     if (a.walk_boxes != 0u) {
         const bool wants_walk = !reuse_hit && may_enter_walk_boxes(a, s.ro, s.rd);
         const uint32_t n_here = (uint32_t)__popcll(__ballot(true));
@@ -1180,6 +1179,7 @@ DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32
         starve = (n_walk != 0u && !run) ? starve + 0x10000u : (starve & 0xffffu);
         if (wants_walk && !run) return STEP_WAIT;
     }
+#endif
     return reuse_hit ? STEP_REUSE : STEP_TRAVERSE;
 }
 
@@ -1331,11 +1331,11 @@ DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& s
         memo_hit_load(a, ls, hit);
     } else if (mode == STEP_TRAVERSE) {
         TIC(t0);
-        hit = intersect_scene<LDS, STATS, TLAS>(a, s.ro, s.rd, stack_of<(LDS && RT_TOTAL_IN_LDS)>(ls), node_tests, tri_tests);
+        hit = intersect_scene<LDS, STATS, TLAS>(a, s.ro, s.rd, stack_of<total_in_lds(LDS)>(ls), node_tests, tri_tests);
         TOC(t0, 0);
         memo_hit_store<STATS>(a, s, ls, hit);
     }
-    return path_end<LDS, (LDS && RT_TOTAL_IN_LDS)>(a, s, ls, mode, hit, n_segments);
+    return path_end<LDS, total_in_lds(LDS)>(a, s, ls, mode, hit, n_segments);
 }
 
 // wgsl:498 + 154-161
@@ -1412,7 +1412,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     const PixelCoord px = pixel_of(a, tile, threadIdx.x & 63u);
     const bool valid = tile_ok && px.valid;
     PixelState s;
-    pixel_begin<(LDS && RT_TOTAL_IN_LDS)>(a, cam, s, ls, px.x, px.y, px.out_row);
+    pixel_begin<total_in_lds(LDS)>(a, cam, s, ls, px.x, px.y, px.out_row);
     pixel_cache_begin(a, a, cam, s, ls);
     uint32_t starve = 0;
     bool active = valid && a.params.rays_per_pixel > 0;
@@ -1421,7 +1421,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     while (active) {
         if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, n_reused_wave, node_tests, tri_tests)) active = false;
     }
-    if (valid) pixel_finish<(LDS && RT_TOTAL_IN_LDS)>(a, s, ls);
+    if (valid) pixel_finish<total_in_lds(LDS)>(a, s, ls);
     if (a.tile_cost && tile_ok) {  // one store per wave: the tile's rays
         uint32_t sum = n_segments;
         for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
@@ -1454,7 +1454,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
     const uint32_t n_items = n_tiles * (a.batch_frames ? a.batch_frames : 1u);  // (frame, tile) pairs, frame-major
     bool exhausted = false;
     PixelState s;
-    pixel_begin<(LDS && RT_TOTAL_IN_LDS)>(a, camera_consts(a), s, ls, 0, 0, 0);
+    pixel_begin<total_in_lds(LDS)>(a, camera_consts(a), s, ls, 0, 0, 0);
     bool active = false;
     uint32_t n_segments = 0, n_reused_wave = 0;
     int node_tests = 0, tri_tests = 0;
@@ -1498,13 +1498,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                     if (px.valid) {
                         DIAG(15);
                         const CameraConsts cam = camera_consts(ca);
-                        pixel_begin<(LDS && RT_TOTAL_IN_LDS)>(ca, cam, s, ls, px.x, px.y, px.out_row, pool_frame);
+                        pixel_begin<total_in_lds(LDS)>(ca, cam, s, ls, px.x, px.y, px.out_row, pool_frame);
                         pixel_cache_begin(a, ca, cam, s, ls);
                         s.meta = ((pull_seq & (COST_SLOTS - 1u)) << 16) | (pool_frame << 19);
                         if (have_samples) {
                             active = true;
                         } else {
-                            pixel_finish<(LDS && RT_TOTAL_IN_LDS)>(ca, s, ls);  // 0 / 0 = NaN, as the shader would store
+                            pixel_finish<total_in_lds(LDS)>(ca, s, ls);  // 0 / 0 = NaN, as the shader would store
                             if (a.tile_cost && pool_frame == 0u) tile_cost_add(a, cost_tbl, s);
                         }
                     }
@@ -1524,7 +1524,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         if (active) {
             if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, n_reused_wave, node_tests, tri_tests)) {
                 DIAG(16);
-                pixel_finish<(LDS && RT_TOTAL_IN_LDS)>(cold_args(), s, ls);
+                pixel_finish<total_in_lds(LDS)>(cold_args(), s, ls);
                 if (a.tile_cost && (s.meta >> 19) == 0u) tile_cost_add(a, cost_tbl, s);
                 active = false;
             }
@@ -1551,7 +1551,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
 // ---------------------------------------------------------------------------
 template <bool LDS, bool TLAS>
 __global__ void __launch_bounds__(BLOCK_THREADS) rt_debug_kernel(const RenderArgs a) {
-    uint32_t* stack = stack_of<(LDS && RT_TOTAL_IN_LDS)>(block_prologue<LDS>(a));
+    uint32_t* stack = stack_of<total_in_lds(LDS)>(block_prologue<LDS>(a));
     const uint32_t tile = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (tile >= a.tiles_x * a.tiles_y) return;
     const PixelCoord px = pixel_of(a, tile, threadIdx.x & 63u);
@@ -1750,7 +1750,7 @@ size_t render_lds_bytes(const RenderArgs& a) {
     size_t stacks = ((size_t)(a.stack_entries ? a.stack_entries : 1u) * (a.stack_wide ? 128u : 64u) + (size_t)a.tlas_entries * 64u) *
                     sizeof(uint32_t) * WAVES_PER_BLOCK;
     size_t cost_tables = 8u * 3u * sizeof(uint32_t) * WAVES_PER_BLOCK;
-    size_t lane_state = (a.lds_scene && RT_TOTAL_IN_LDS) ? (size_t)LANE_STATE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
+    size_t lane_state = total_in_lds(a.lds_scene != 0u) ? (size_t)LANE_STATE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
     size_t cache = a.pixel_cache == 1u ? (size_t)PIXEL_MEMO_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
     // (= 4 x wave_region_dwords + the cost tables, see the LDS map)
     return stacks + cost_tables + lane_state + cache + (a.lds_scene ? a.lay.bytes : (size_t)a.top_count * WIDE_REC_BYTES);
