@@ -67,17 +67,10 @@ struct rt_handle {
     std::vector<int> multi_comm_devices;  // the device list the communicators were made for
     std::set<int> multi_peers_enabled;
     int multi_rccl = 1;  // option "multi_rccl"
-    // walk vote (RenderArgs::walk_box): candidate boxes found at upload, options
-    float walk_box[RT_WALK_BOXES][6] = {};
     uint32_t top_base = 0, top_available = 0;  // breadth-first numbered top records of the biggest mesh's BVH
     // option "lds_top": 0 off (default: measured slower), -1 what fits beside the stacks at full
     // occupancy, N records
     int lds_top = 0;
-    uint32_t n_walk_boxes = 0, n_walk_coarse = 0;
-    int walk_depth = 3;  // option "walk_depth": BVH level of a big mesh's fine walk boxes (1 = the root's children only)
-    bool walk_boxes_are_big_meshes = false;
-    int walk_vote = 0;  // option "walk_vote": 0 off (default: measured a wash), 1 on, -1 on for big meshes
-    int walk_eighths = 2, walk_patience = 3;
     float4* own_image = nullptr;  // allocated by rt_create; `image` may be rebound
     float4* multi_gathered = nullptr;  // rt_render_multi root: [world][pad_texels]
     float4* multi_frame = nullptr;     // rt_render_multi root: assembled full frame
@@ -619,76 +612,6 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         const uint32_t tlas_entries = tlas.empty() ? 1u : tlas_depth + 2u;
         const bool has_tlas = !tlas.empty();
 
-        // ---- walk-vote boxes (scheduling heuristic only, see RenderArgs::walk_box) ----------
-        // Candidates: single-mesh items with a large BVH (their root's two child boxes) and the members
-        // of forests with more than a couple of internal nodes (their root box), in world space.
-        struct WalkCand { uint32_t weight; float box[6]; bool big; };
-        std::vector<WalkCand> walk_cands, walk_fine;
-        {
-            auto world_box = [&](const rt_mesh_uniform& m, const float* mn, const float* mx, float out[6]) {
-                for (int k = 0; k < 3; ++k) { out[k] = FLT_MAX; out[3 + k] = -FLT_MAX; }
-                for (int c = 0; c < 8; ++c) {
-                    const float p[3] = {(c & 1) ? mx[0] : mn[0], (c & 2) ? mx[1] : mn[1], (c & 4) ? mx[2] : mn[2]};
-                    for (int k = 0; k < 3; ++k) {  // column-major model_to_world[col][row]
-                        const float w = m.model_to_world[0][k] * p[0] + m.model_to_world[1][k] * p[1] + m.model_to_world[2][k] * p[2] + m.model_to_world[3][k];
-                        if (w < out[k]) out[k] = w;
-                        if (w > out[3 + k]) out[3 + k] = w;
-                    }
-                }
-            };
-            uint32_t best_big = 0, best_big_mesh = 0xffffffffu;
-            for (const Item& it : items) {
-                if (it.kind & ITEM_TLAS) continue;
-                if (it.kind & ITEM_FOREST) {
-                    for (uint32_t f = 0; f < it.n; ++f) {
-                        uint32_t mi;
-                        memcpy(&mi, &forest_entries[it.a + f].q[0].y, 4);
-                        const uint32_t internal = (mi + 1 < n_meshes ? wide_base[mi + 1] : (uint32_t)wide.size()) - wide_base[mi];
-                        if (internal < 4) continue;
-                        const rt_node& r = nodes[meshes[mi].node_offset];
-                        WalkCand c{internal, {}, false};
-                        world_box(meshes[mi], r.aabb_min, r.aabb_max, c.box);
-                        walk_cands.push_back(c);
-                    }
-                    continue;
-                }
-                const uint32_t mi = it.a;
-                if (root_count[mi] != 0) continue;
-                const uint32_t internal = (mi + 1 < n_meshes ? wide_base[mi + 1] : (uint32_t)wide.size()) - wide_base[mi];
-                if (internal < 64) continue;
-                if (internal > best_big) { best_big = internal; best_big_mesh = mi; }
-            }
-            if (best_big_mesh != 0xffffffffu) {
-                // the biggest mesh decides: coarse = its root's two child boxes, fine = the boxes `walk_depth` levels down
-                walk_cands.clear();
-                const rt_mesh_uniform& m = meshes[best_big_mesh];
-                const rt_node* mn = nodes + m.node_offset;
-                std::vector<std::pair<uint32_t, int>> level{{mn[0].left, 1}, {mn[0].right, 1}};
-                for (auto& [ch, d] : level) {
-                    WalkCand c{best_big, {}, true};
-                    world_box(m, mn[ch].aabb_min, mn[ch].aabb_max, c.box);
-                    walk_cands.push_back(c);
-                }
-                std::vector<uint32_t> fine;
-                while (!level.empty()) {
-                    auto [nd, d] = level.back();
-                    level.pop_back();
-                    if (d >= h->walk_depth || mn[nd].count > 0) { fine.push_back(nd); continue; }
-                    level.push_back({mn[nd].left, d + 1});
-                    level.push_back({mn[nd].right, d + 1});
-                }
-                if (h->walk_depth > 1 && fine.size() + 2 <= RT_WALK_BOXES)
-                    for (uint32_t nd : fine) {
-                        WalkCand c{best_big, {}, true};
-                        world_box(m, mn[nd].aabb_min, mn[nd].aabb_max, c.box);
-                        walk_fine.push_back(c);
-                    }
-            } else {
-                std::stable_sort(walk_cands.begin(), walk_cands.end(), [](const WalkCand& x, const WalkCand& y) { return x.weight > y.weight; });
-                if (walk_cands.size() > 4) walk_cands.resize(4);
-            }
-        }
-
         // ---- blob layout ------------------------------------------------------
         SceneLayout lay{};
         uint64_t off = 0;
@@ -801,14 +724,6 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->n_items = (uint32_t)items.size();
         h->top_base = top_mesh_base;
         h->top_available = top_mesh_records >= 64 ? std::min<uint32_t>(top_mesh_records, 2048u) : 0u;
-        h->n_walk_coarse = (uint32_t)walk_cands.size();
-        walk_cands.insert(walk_cands.end(), walk_fine.begin(), walk_fine.end());
-        h->n_walk_boxes = (uint32_t)walk_cands.size();
-        h->walk_boxes_are_big_meshes = false;
-        for (size_t k = 0; k < walk_cands.size(); ++k) {
-            memcpy(h->walk_box[k], walk_cands[k].box, sizeof(float) * 6);
-            if (walk_cands[k].big) h->walk_boxes_are_big_meshes = true;
-        }
         // LDS residency: blob + the four waves' stacks, cost tables and lane state within the
         // per-workgroup budget (the primary-ray memo goes to LDS only if it still fits, see render_impl)
         uint64_t stacks = ((uint64_t)h->stack_entries * (h->stack_wide ? 128u : 64u) + (uint64_t)h->tlas_entries * 64u) * sizeof(uint32_t) * WAVES_PER_BLOCK +
@@ -896,21 +811,9 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         h->cull_roots = value;
     } else if (n == "lds_scene") {
         h->force_global = value ? 0 : 1;
-    } else if (n == "walk_vote") {
-        if (value < -1 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "walk_vote must be -1 (auto), 0 or 1");
-        h->walk_vote = value;
     } else if (n == "lds_top") {
         if (value < -1 || value > 2048) return fail(h, RT_ERR_INVALID_ARGUMENT, "lds_top must be -1 (auto), 0 (off) or a record count <= 2048");
         h->lds_top = value;
-    } else if (n == "walk_depth") {
-        if (value < 1 || value > 3) return fail(h, RT_ERR_INVALID_ARGUMENT, "walk_depth must be 1..3 (takes effect at the next rt_upload_scene)");
-        h->walk_depth = value;
-    } else if (n == "walk_eighths") {
-        if (value < 0 || value > 8) return fail(h, RT_ERR_INVALID_ARGUMENT, "walk_eighths must be 0..8");
-        h->walk_eighths = value;
-    } else if (n == "walk_patience") {
-        if (value < 0 || value > 60000) return fail(h, RT_ERR_INVALID_ARGUMENT, "walk_patience must be 0..60000");
-        h->walk_patience = value;
     } else if (n == "multi_rccl") {
         if (value < 0 || value > 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "multi_rccl must be 0 (peer copies), 1 (RCCL between distinct devices) or 2 (RCCL always)");
         h->multi_rccl = value;
@@ -1036,15 +939,6 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         if (h->lds_top > 0) fit = (uint32_t)h->lds_top;
         a.top_count = std::min(fit, h->top_available);
     }
-    // walk vote: automatic for scenes with a big mesh (read from global memory: long, latency-bound walks)
-    a.walk_boxes = 0;
-    if (h->n_walk_boxes && params->debug_flag == 0 && (h->walk_vote == 1 || (h->walk_vote < 0 && h->walk_boxes_are_big_meshes))) {
-        a.walk_boxes = h->n_walk_boxes;
-        a.walk_coarse = h->n_walk_coarse;
-        memcpy(a.walk_box, h->walk_box, sizeof(a.walk_box));
-    }
-    a.walk_eighths = (uint32_t)h->walk_eighths;
-    a.walk_patience = (uint32_t)h->walk_patience;
     a.persistent_blocks = h->persistent_blocks;
     {
         // workgroups that fit a CU's 160 KiB of LDS (BLOCKS_PER_CU when the register budget is the limit)

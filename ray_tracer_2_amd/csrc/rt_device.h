@@ -112,11 +112,6 @@ constexpr bool total_in_lds(bool lds_scene) { return RT_TOTAL_IN_LDS != 0 && (ld
 // one word = mat_off | hit | backface << 1 | ray valid << 2 | hit valid << 3.
 constexpr uint32_t PIXEL_MEMO_DWORDS = 13;
 
-constexpr uint32_t RT_WALK_BOXES = 12;
-#ifndef RT_WALK_VOTE
-#define RT_WALK_VOTE 1   // 0: compile the walk vote out of the render kernels (A/B of its register cost)
-#endif
-
 struct DTexture {
     const uint8_t* rgba8;
     uint32_t width, height;
@@ -171,22 +166,10 @@ struct RenderArgs {
     // order afterwards.  0 = a plain one-frame launch that blends in place.
     uint32_t batch_frames;
     unsigned long long batch_stride;  // texels between the scratch frames
-    // Walk vote (pure scheduling, like the intersection vote): world-space boxes around the parts of the
-    // scene whose traversal is long and that few rays enter (a big mesh's top boxes, the BVH meshes of a
-    // forest).  A lane whose ray may enter one waits until enough lanes of its wave want the same (or
-    // somebody has waited walk_patience iterations), so that the long walks run with many lanes
-    // instead of a handful while the rest of the wave idles.  The test is a heuristic (approximate
-    // reciprocal): it only decides WHEN a lane traverses, never what it computes.
     // LDS-staged top of a big mesh's BVH (scenes read from global memory): wide records top_base ..
     // top_base + top_count - 1 -- the first levels of the biggest mesh, numbered breadth-first at upload
     // -- are copied into LDS by every workgroup (coalesced 16-byte loads) and read from there.
     uint32_t top_base, top_count;
-    uint32_t walk_boxes;    // 0 = no walk vote
-    uint32_t walk_coarse;   // the first walk_coarse boxes are tested first; only a ray that may enter one of them is
-                            // tested against the remaining (finer) boxes, which then decide; == walk_boxes: one level
-    uint32_t walk_eighths;  // run when waiting lanes * 8 >= lanes here * walk_eighths
-    uint32_t walk_patience;
-    float walk_box[RT_WALK_BOXES][6];  // min.xyz, max.xyz
 };
 
 constexpr uint32_t RT_MAX_BATCH_FRAMES = 32;

@@ -1083,28 +1083,6 @@ enum : uint32_t {
     STEP_TRAVERSE = 3,  // intersect the scene
 };
 
-// Walk vote heuristic: may the ray (ro, rd) enter one of the launch's walk boxes?  Slab test with an
-// approximate reciprocal (v_rcp_f32): scheduling only, see RenderArgs::walk_box.
-DEV bool may_enter_walk_boxes(const RenderArgs& a, f3 ro, f3 rd) {
-    const f3 inv{__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z)};
-    auto hits = [&](uint32_t k0, uint32_t k1) {
-        bool any = false;
-        for (uint32_t k = k0; k < k1; ++k) {
-            const float* b = a.walk_box[k];
-            const float t1x = (b[0] - ro.x) * inv.x, t2x = (b[3] - ro.x) * inv.x;
-            const float t1y = (b[1] - ro.y) * inv.y, t2y = (b[4] - ro.y) * inv.y;
-            const float t1z = (b[2] - ro.z) * inv.z, t2z = (b[5] - ro.z) * inv.z;
-            const float t_near = max_(max_(min_(t1x, t2x), min_(t1y, t2y)), min_(t1z, t2z));
-            const float t_far = min_(min_(max_(t1x, t2x), max_(t1y, t2y)), max_(t1z, t2z));
-            any = any || (t_far >= t_near && t_far > 0.0f);
-        }
-        return any;
-    };
-    bool any = hits(0u, a.walk_coarse);
-    if (a.walk_coarse < a.walk_boxes && any) any = hits(a.walk_coarse, a.walk_boxes);
-    return any;
-}
-
 template <bool STATS>
 DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve) {
     const int32_t nb = a.params.number_of_bounces;
@@ -1159,27 +1137,13 @@ DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32
     // it (or somebody has already waited); the waiting lanes simply take their turn in the
     // next iteration, by which time the memoised-primary lanes have moved on to secondary
     // segments and want it too.  Pure scheduling: no lane's sequence of operations changes.
-    // (`starve` holds both votes' wait counts: bits 0-15 this one, bits 16-31 the walk vote)
     if (cache_on) {
         const uint32_t n_here = (uint32_t)__popcll(__ballot(true));
         const uint32_t n_want = (uint32_t)__popcll(__ballot(!reuse_hit));
-        const bool run = n_want * 8u >= n_here * a.vote_eighths || (starve & 0xffffu) >= a.vote_patience;
-        starve = (n_want != 0u && !run) ? starve + 1u : (starve & 0xffff0000u);
+        const bool run = n_want * 8u >= n_here * a.vote_eighths || starve >= a.vote_patience;
+        starve = (n_want != 0u && !run) ? starve + 1u : 0u;
         if (!reuse_hit && !run) return STEP_WAIT;  // nothing about this lane has changed
     }
-    // Walk vote.  The long, sparsely entered walks (RenderArgs::walk_box) cost the wave their full length
-    // whenever a single lane takes one; a lane whose ray may take one waits -- with its path state
-    // untouched, it has not started the segment -- until enough lanes of the wave want the same.
-#if RT_WALK_VOTE
-    if (a.walk_boxes != 0u) {
-        const bool wants_walk = !reuse_hit && may_enter_walk_boxes(a, s.ro, s.rd);
-        const uint32_t n_here = (uint32_t)__popcll(__ballot(true));
-        const uint32_t n_walk = (uint32_t)__popcll(__ballot(wants_walk));
-        const bool run = n_walk * 8u >= n_here * a.walk_eighths || (starve >> 16) >= a.walk_patience;
-        starve = (n_walk != 0u && !run) ? starve + 0x10000u : (starve & 0xffffu);
-        if (wants_walk && !run) return STEP_WAIT;
-    }
-#endif
     return reuse_hit ? STEP_REUSE : STEP_TRAVERSE;
 }
 
