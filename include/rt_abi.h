@@ -322,8 +322,9 @@ typedef struct rt_scene rt_scene;
 
 /* ≙ Scene::from_name + Scene::instantiate_scene (scene.rs:1003,179).
  * name: "cornell_box", "room", "room_2", "metal", "balls", "sponza",
- * "texture_test", "obj_test" (random_balls is unseeded in the reference and is
- * not reproduced).  assets_dir ≙ CARGO_MANIFEST_DIR/assets (asset.rs:50,108). */
+ * "texture_test", "obj_test", "random_balls" / "random_balls:<seed>" (the reference draws this
+ * scene from an OS-seeded generator, scene.rs:403, so its own runs never agree; this build makes
+ * the same draws from a seeded one: a documented divergence).  assets_dir ≙ CARGO_MANIFEST_DIR/assets (asset.rs:50,108). */
 int rt_scene_load_builtin(const char* name, const char* assets_dir, rt_scene** out);
 
 /* Scene-definition API ≙ SceneDefinition::{set_camera, add_mesh, add_sphere}

@@ -12,6 +12,7 @@
 #include "scene.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -540,6 +541,45 @@ bool load_builtin_scene(const std::string& name, const std::string& assets_dir,
         d.sphere({-0.5f, -0.9f, 1.55f}, 0.35f, with_color(NEW, 0, 0, 1, 1));
         d.sphere({-3.46f, -15.88f, 2.76f}, 15.0f, with_color(NEW, 0.5f, 0.0f, 0.8f, 1));
         d.sphere({-7.44f, -0.72f, 20.0f}, 15.0f, with_emissive(with_color(NEW, 0.1f, 0.1f, 0.1f, 0.0f), 1, 1, 1, 1, 1.0f));
+    } else if (name == "random_balls" || name.rfind("random_balls:", 0) == 0) {  // scene.rs:365-444
+        // The reference draws this scene from rand::rng() (ThreadRng, seeded by the OS, scene.rs:403), so no two
+        // of its runs agree and none can be reproduced.  Documented divergence: the same construction -- the
+        // same draws in the same order, the same thresholds and ranges -- from a SEEDED generator, the shader's
+        // own PCG variant (wgsl:195-200); "random_balls:<seed>" picks the seed (default 0).  f32 draws follow
+        // rand 0.9's StandardUniform (24 random bits in [0, 1)); random_range(a..b) is a + (b - a) * that.
+        uint32_t state = 0;
+        if (name.size() > 13) state = (uint32_t)std::strtoul(name.c_str() + 13, nullptr, 10);
+        auto next_u32 = [&]() {
+            state = state * 747796405u + 2891336453u;
+            uint32_t r = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+            return (r >> 22u) ^ r;
+        };
+        auto unit = [&]() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); };
+        auto range = [&](float lo, float hi) { return lo + (hi - lo) * unit(); };
+        cam.transform = Transform::cam({13, 2, 3}, {0, 0, 0});
+        cam.fov = 20; cam.near_plane = 0.1f; cam.far_plane = 100; cam.focus_dist = 10.0f;
+        d.sphere({0, -1000, 0}, 1000.0f, with_color(NEW, 0.5f, 0.5f, 0.5f, 1));
+        d.sphere({0, 1, 0}, 1.0f, with_glass(NEW, 1.5f));
+        d.sphere({-4, 1, 0}, 1.0f, with_color(NEW, 0.4f, 0.2f, 0.1f, 1));
+        d.sphere({4, 1, 0}, 1.0f, with_smooth(with_specular(with_color(NEW, 0.7f, 0.6f, 0.5f, 1), 0.7f, 0.6f, 0.5f, 1, 1.0f), 1.0f));
+        for (int a = -11; a < 11; ++a)
+            for (int b = -11; b < 11; ++b) {
+                const float mat = unit();
+                const float cx = (float)a + 0.9f * unit(), cz = (float)b + 0.9f * unit();
+                const float dx = cx - 4.0f, dy = 0.2f - 0.2f, dz = cz - 0.0f;
+                if (std::sqrt((dx * dx + dy * dy) + dz * dz) > 0.9f) {
+                    if (mat < 0.8f) {
+                        const float r = unit(), g = unit(), bl = unit();
+                        d.sphere({cx, 0.2f, cz}, 0.2f, with_color(NEW, r, g, bl, 1));
+                    } else if (mat < 0.95f) {
+                        const float r = range(0.5f, 1.0f), g = range(0.5f, 1.0f), bl = range(0.5f, 1.0f);
+                        const float fuzz = range(0.0f, 0.5f);
+                        d.sphere({cx, 0.2f, cz}, 0.2f, with_specular(with_color(NEW, r, g, bl, 1), 1, 1, 1, 1, fuzz));
+                    } else {
+                        d.sphere({cx, 0.2f, cz}, 0.2f, with_glass(NEW, 1.3f));
+                    }
+                }
+            }
     } else if (name == "sponza" || name == "bugatti") {  // scene.rs:864-910, 934-983
         const bool sp = name == "sponza";
         cam.transform = sp ? Transform::cam({0, 4, 0}, {0, 4, 1}) : Transform::cam({0, 0, 0}, {0, 0, 1});

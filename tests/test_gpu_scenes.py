@@ -29,7 +29,7 @@ def render_both(rt, oracle, tracer, arrays, params):
     return gpu, ref, tracer.stats(), st
 
 
-@pytest.mark.parametrize("name", ["room", "metal", "balls"])
+@pytest.mark.parametrize("name", ["room", "metal", "balls", "random_balls:3"])
 @pytest.mark.parametrize("variant", [0, 1])
 def test_sphere_and_glass_scenes(rt, oracle, tracer, name, variant):
     """scene.rs library scenes: spheres (ray_sphere), glass (refract, Beer-Lambert,

@@ -187,6 +187,31 @@ def test_builtin_scene_library(rt):
         rt.Scene.from_name("room_2", DATA)   # Dragon_80K.obj is absent: clean error, no abort
 
 
+def test_random_balls_is_the_reference_construction_from_a_seeded_generator(rt):
+    """scene.rs:365-444: floor + three big spheres + up to 22 x 22 small ones on a jittered grid, 80 % diffuse /
+    15 % metal / 5 % glass, none closer than 0.9 to (4, 0.2, 0).  The reference seeds from the OS; here the
+    seed is part of the name and the scene is reproducible."""
+    a = rt.Scene.from_name("random_balls", DATA)
+    b = rt.Scene.from_name("random_balls:0", DATA)
+    c = rt.Scene.from_name("random_balls:7", DATA)
+    sa, sb, sc = a.spheres(), b.spheres(), c.spheres()
+    assert sa.tobytes() == sb.tobytes() and sa.tobytes() != sc.tobytes()
+    assert 4 + 400 < len(sa) <= 4 + 484 <= 500           # ray_tracer.rs:16 caps spheres at 500
+    assert sa["pos"][0].tolist() == [0, -1000, 0] and sa["radius"][0] == 1000
+    small = sa[4:]
+    assert np.all(small["radius"] == np.float32(0.2)) and np.all(small["pos"][:, 1] == np.float32(0.2))
+    assert np.all(np.linalg.norm(small["pos"] - np.float32([4, 0.2, 0]), axis=1) > 0.9)
+    gx, gz = np.floor(small["pos"][:, 0]), np.floor(small["pos"][:, 2])
+    assert gx.min() >= -11 and gx.max() <= 10 and gz.min() >= -11 and gz.max() <= 10
+    glass = small["material"]["flag"] == 1
+    metal = (~glass) & (small["material"]["specular"] != np.float32(0.1))
+    assert 0.01 < glass.mean() < 0.12 and 0.07 < metal.mean() < 0.25
+    assert np.all(small["material"]["ior"][glass] == np.float32(1.3))
+    assert np.all((small["material"]["color"][metal][:, :3] >= 0.5) & (small["material"]["color"][metal][:, :3] < 1.0))
+    u = a.uniform()
+    assert u.spheres == len(sa) and u.meshes == 0
+
+
 def test_export_rgba8_against_the_oracle_restatement(rt, oracle):
     """rt_export_rgba8 == the literal restatement of app.rs:408-460 (reversed x loop + two flips) on a full
     golden frame and on the values the cast rules decide: NaN, +-inf, negatives, > 1, subnormals, values whose
