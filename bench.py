@@ -250,11 +250,15 @@ def main():
         if world == 1 and (W, H) == (WIDTH, HEIGHT) and os.path.exists(tpath):
             from ray_tracer_2_amd.build import source_hash
             tj = json.load(open(tpath))
-            if tj.get("source_hash") != source_hash() or tj.get("frames_per_launch") != frames_per_launch \
+            if tj.get("source_hash") != source_hash() or (tj.get("frames_per_launch", 1) > 1) != (frames_per_launch > 1) \
                     or args.variant is not None or args.blocks is not None or os.environ.get("RT2_OPTIONS"):
-                stale = f"stale profile: {tj.get('source')} was taken on another build or batch size"
+                stale = f"stale profile: {tj.get('source')} was taken on another build or launch mode"
             else:
-                traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
+                # counters are kept per frame (they do not depend on how many frames share a launch) and
+                # scaled to this run's frames per launch
+                scale = frames_per_launch / tj.get("frames_per_launch", 1)
+                traffic = tj["bytes_per_launch"] * scale
+                traffic_src = tj["source"] + (f", per frame x {frames_per_launch:g} frames per launch" if scale != 1 else "")
                 if "valu_instructions_per_launch" in tj:
                     # The bound that matters: VALU issue.  Peak = the guide's: a SIMD-32
                     # issues one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md; that is what
@@ -262,7 +266,7 @@ def main():
                     # useful_lane_frac = issue_frac x active lanes per instruction / 64.
                     simds = torch.cuda.get_device_properties(device).multi_processor_count * 4
                     clock = tj.get("shader_clock_ghz", 2.4)
-                    rate = tj["valu_instructions_per_launch"] / (launch_ms * 1e-3) / 1e9
+                    rate = tj["valu_instructions_per_launch"] * scale / (launch_ms * 1e-3) / 1e9
                     peak = simds * clock / 2.0
                     lanes = tj.get("valu_lane_utilisation")
                     valu = {"bound": "valu_issue", "achieved": rate, "peak": peak, "unit": "G wave-instructions/s",

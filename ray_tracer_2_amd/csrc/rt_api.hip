@@ -123,9 +123,10 @@ struct rt_handle {
     int force_stack_wide = -1;  // option "stack_wide": -1 auto, 0 one-dword entries when legal, 1 two-dword entries
     bool has_forest = false;
     int pixel_cache_opt = 1;  // option "pixel_cache"
-    int vote_eighths = 6, vote_patience = 1;  // options "vote_eighths", "vote_patience"
+    int vote_eighths = 6, vote_patience = 3;  // options "vote_eighths", "vote_patience"
     int use_tlas = 1;  // option "tlas": 0 = every mesh is a single item (takes effect at the next upload)
     int use_forest = 1;  // option "forest": 0 = no forest items (takes effect at the next upload)
+    int use_flat2 = 1;   // option "flat2": 0 = meshes with a two-leaf BVH are not run as straight-line items (next upload)
     int tlas_min = (int)TLAS_MIN_MESHES;  // option "tlas_min": smallest run of meshes that gets a top-level tree
     rt_camera_uniform camera{};
     int count_tests = 0;
@@ -555,6 +556,12 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 i0 = i1;
             }
         const bool allow_forest = h->use_forest && !any_tlas && n_meshes < 16;
+        // meshes whose root has two leaf children run as straight-line code in the few-mesh kernels (ITEM_FLAT2)
+        auto is_flat2 = [&](uint32_t i) {
+            if (!h->use_flat2 || any_tlas || n_meshes >= 16 || root_count[i] != 0 || deep[i]) return false;
+            const rt_node* mn = nodes + meshes[i].node_offset;
+            return mn[mn[0].left].count > 0 && mn[mn[0].right].count > 0;
+        };
         for (uint32_t i0 = 0; i0 < n_meshes;) {
             uint32_t i1 = i0 + 1;
             while (i1 < n_meshes && memcmp(meshes[i1].world_to_model, meshes[i0].world_to_model, 64) == 0) ++i1;
@@ -570,7 +577,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 size_t g = 0;
                 for (uint32_t i = i0; i < i1; ++i) {
                     if (g < grouped.size() && grouped[g] == i) { ++g; continue; }
-                    if (root_count[i] == 0 && !deep[i] && memcmp(meshes[i].model_to_world, meshes[i0].model_to_world, 64) == 0)
+                    if (root_count[i] == 0 && !deep[i] && !is_flat2(i) && memcmp(meshes[i].model_to_world, meshes[i0].model_to_world, 64) == 0)
                         forest.push_back(i);
                 }
                 if (forest.size() < 2) forest.clear();
@@ -581,7 +588,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             for (uint32_t i = i0; i < i1; ++i) {
                 if (g < grouped.size() && grouped[g] == i) { ++g; continue; }
                 if (fo < forest.size() && forest[fo] == i) { ++fo; continue; }
-                items.push_back(Item{flag(), i, i0, 1});
+                items.push_back(Item{flag() | (is_flat2(i) ? ITEM_FLAT2 : 0u), i, i0, 1});
             }
             for (size_t f0 = 0; f0 < forest.size(); f0 += FOREST_MAX_MEMBERS) {
                 const size_t f1 = std::min(forest.size(), f0 + (size_t)FOREST_MAX_MEMBERS);
@@ -803,6 +810,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         h->force_stack_wide = value;
     } else if (n == "forest") {
         h->use_forest = value ? 1 : 0;
+    } else if (n == "flat2") {
+        h->use_flat2 = value ? 1 : 0;
     } else if (n == "tlas_min") {
         if (value < 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "tlas_min must be >= 2");
         h->tlas_min = value;
@@ -1082,9 +1091,13 @@ static int render_frames_impl(rt_handle* h, const rt_params* params, uint32_t n_
     if (!h || !params) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
     rt_params p = *params;
     uint32_t done = 0;
+    // batches of equal size (20 frames at 16 per launch: 10 + 10, not 16 + 4)
+    const uint32_t cap = (uint32_t)h->batch_frames_opt;
+    const uint32_t launches = (n_frames + cap - 1) / cap;
+    const uint32_t per = launches ? (n_frames + launches - 1) / launches : 0;
     while (done < n_frames) {
         uint32_t n = n_frames - done;
-        if (n > (uint32_t)h->batch_frames_opt) n = (uint32_t)h->batch_frames_opt;
+        if (n > per) n = per;
         if (params->debug_flag != 0 || params->rays_per_pixel <= 0) n = 1;
         p.frames = (int32_t)((uint32_t)params->frames + done);
         const int rc = render_impl(h, &p, rank, world, n >= 2 ? n : 0u);

@@ -45,7 +45,11 @@ struct SceneLayout {
 //        internal, non-deep root that share both matrices; each lane walks the members whose root
 //        box it hits one after the other, independently of the other lanes (traverse_forest).
 constexpr uint32_t ITEM_BYTES = 32;
-enum : uint32_t { ITEM_TLAS = 1u, ITEM_NEW_XFORM = 2u, ITEM_FOREST = 4u };
+//   flat (ITEM_FLAT2, an attribute of a single-mesh item): the mesh's BVH is a root with two LEAF children
+//        (a quad split into its two triangles, ...).  Its whole traversal is two box tests and the leaves' triangles,
+//        near leaf first: the few-mesh kernels run it as straight-line code with every lane of the wave in step,
+//        no stack and no loop (traverse_flat2), instead of as a forest member or a mesh walk.
+enum : uint32_t { ITEM_TLAS = 1u, ITEM_NEW_XFORM = 2u, ITEM_FOREST = 4u, ITEM_FLAT2 = 8u };
 // Forest member entry, 3 x 16 B: q0 = (root wide index, mesh index, flags, 0), q1/q2 = the root's
 // packed box (as in a wide record).  flags: DMESH_GLASS, FOREST_CULLABLE = the root box provably
 // contains the boxes of the root's children (so missing it means missing the mesh).

@@ -428,6 +428,41 @@ DEV void traverse_mesh(const RenderArgs& a, uint32_t root_idx, uint32_t root_cou
     TOC(t16, 16);
 }
 
+// wgsl:292-335 for a mesh whose root has two leaf children (ITEM_FLAT2), as straight-line code.  What the
+// shader's loop does on such a tree: both child boxes are tested against the initial closest distance
+// (INF); the far one is pushed if hit, the near one visited next if hit, and a popped entry is not tested
+// again -- so the near leaf's triangles are tested iff its box is hit, then the far leaf's iff its box is hit,
+// each triangle against the closest hit so far.  Same tests, same order, same counters; no stack, no loop
+// over nodes, and every lane of the wave does it together.
+template <bool LDS, bool STATS>
+DEV void traverse_flat2(const RenderArgs& a, uint32_t root_rec, bool cull, f3 lo, f3 ld, f3 inv, MeshBest& best,
+                        int& node_tests, int& tri_tests) {
+    float4 q0, q1, q2, q3;
+    load_wide<LDS>(a, root_rec, q0, q1, q2, q3);
+    const float da = aabb_dist(lo, inv, q0, q1, INF), db = aabb_dist(lo, inv, q2, q3, INF);
+    if (STATS) node_tests += 2;
+    const bool left_closer = da < db;
+    const float near_d = left_closer ? da : db, far_d = left_closer ? db : da;
+    // (indices and counts of the two leaves are the same in every lane)
+    const uint32_t a_i = __builtin_amdgcn_readfirstlane(fbits(q1.z)), a_c = __builtin_amdgcn_readfirstlane(fbits(q1.w));
+    const uint32_t b_i = __builtin_amdgcn_readfirstlane(fbits(q3.z)), b_c = __builtin_amdgcn_readfirstlane(fbits(q3.w));
+    const uint32_t first_i = left_closer ? a_i : b_i, second_i = left_closer ? b_i : a_i;
+    const uint32_t first_c = near_d < INF ? (left_closer ? a_c : b_c) : 0u;
+    const uint32_t second_c = far_d < INF ? (left_closer ? b_c : a_c) : 0u;
+    if (STATS) tri_tests += (int)(first_c + second_c);
+    const uint32_t tri0 = a.lay.tri_off, c_max = a_c > b_c ? a_c : b_c;
+    for (uint32_t j = 0; j < c_max; ++j)
+        if (j < first_c) {
+            const uint32_t t = tri0 + (first_i + j) * TRI_ISECT_BYTES;
+            tri_test<8>(lo, ld, ld4<LDS>(a, t), ld4<LDS>(a, t + 16), ld4<LDS>(a, t + 32), cull, first_i + j, best);
+        }
+    for (uint32_t j = 0; j < c_max; ++j)
+        if (j < second_c) {
+            const uint32_t t = tri0 + (second_i + j) * TRI_ISECT_BYTES;
+            tri_test<8>(lo, ld, ld4<LDS>(a, t), ld4<LDS>(a, t + 16), ld4<LDS>(a, t + 32), cull, second_i + j, best);
+        }
+}
+
 // A forest item (rt_device.h): meshes with an internal root that share one local space.  The
 // shader visits them one after the other with all lanes in step; here every lane first marks
 // the members whose root box its ray can hit, then walks ITS members back to back, so lanes
@@ -711,7 +746,18 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             continue;
         }
         if constexpr (!TLAS) {
-            visit_mesh(ia, ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16));
+            const float4 hdr = ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16);
+            if (kind & ITEM_FLAT2) {
+                MeshBest b;
+                b.t = INF;
+                b.tri = 0xffffffffu;
+                b.u = b.v = b.w = b.det = 0.0f;
+                traverse_flat2<LDS, STATS>(a, __builtin_amdgcn_readfirstlane(fbits(hdr.y)), (fbits(hdr.x) & DMESH_GLASS) == 0, lo, ld, inv,
+                                           b, node_tests, tri_tests);
+                if (b.tri != 0xffffffffu) accept_mesh_hit(ia, b);
+            } else {
+                visit_mesh(ia, hdr);
+            }
         } else {
             // Many-mesh kernels: one traversal loop serves single meshes (a one-entry stack)
             // and top-level trees, so the mesh visit is instantiated once.
@@ -833,8 +879,16 @@ struct PixelCoord {
 };
 
 template <class A>
+DEV PixelCoord pixel_at(const A& a, uint32_t tx, uint32_t ty, uint32_t w);
+
+template <class A>
 DEV PixelCoord pixel_of(const A& a, uint32_t tile, uint32_t w) {
-    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    return pixel_at(a, tile % a.tiles_x, tile / a.tiles_x, w);
+}
+
+// pixel w of the tile in column tx, local tile row ty
+template <class A>
+DEV PixelCoord pixel_at(const A& a, uint32_t tx, uint32_t ty, uint32_t w) {
     PixelCoord p;
     p.x = tx * 8u + (w & 7u);
     const uint32_t strip = ty * a.strip_world + a.strip_rank;  // global 8-row strip
@@ -1415,6 +1469,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
 
     uint32_t pool_base = 0, pool_left = 0;  // wave-uniform: pixels left in the current tile
     uint32_t pool_frame = 0;                // wave-uniform: the current tile's frame inside a frame batch
+    uint32_t pool_txy = 0;                  // wave-uniform: the current tile's column | (local) row << 16, divided out once per pull
     const uint32_t n_items = n_tiles * (a.batch_frames ? a.batch_frames : 1u);  // (frame, tile) pairs, frame-major
     bool exhausted = false;
     PixelState s;
@@ -1447,6 +1502,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                     if (a.tile_order) t = a.tile_order[t];  // heaviest tiles first (an earlier frame's cost)
                     pool_base = t * 64u;
                     pool_left = 64u;
+                    {
+                        const uint32_t ty = t / a.tiles_x;
+                        pool_txy = (t - ty * a.tiles_x) | (ty << 16);
+                    }
                     pull_seq += 1;
                     // (a batch records the costs of its first frame)
                     if (a.tile_cost && lane == 0 && pool_frame == 0u) tile_cost_pull(a, cost_tbl, pull_seq & (COST_SLOTS - 1u), t);
@@ -1458,7 +1517,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                 if (!active && rank < pool_left) {
                     const uint32_t q = pool_base + rank;
                     ColdArgs& ca = cold_args();
-                    const PixelCoord px = pixel_of(ca, q >> 6, q & 63u);
+                    const PixelCoord px = pixel_at(ca, pool_txy & 0xffffu, pool_txy >> 16, q & 63u);  // (q >> 6 is the pulled tile)
                     if (px.valid) {
                         DIAG(15);
                         const CameraConsts cam = camera_consts(ca);

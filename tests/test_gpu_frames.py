@@ -38,7 +38,7 @@ def test_render_frames_equals_sequential_frames(rt, tracer, cornell, f0, n, batc
     finally:
         tracer.set_option("batch_frames", 16)
     assert np.array_equal(bits(got), bits(want))
-    assert st.frames == n and st.launches == -(-n // batch) and st.paths == w * h * 4 * n
+    assert st.frames == n and st.launches == -(-n // batch) and st.paths == w * h * 4 * n   # equal batches
 
 
 def test_render_frames_against_the_oracle(rt, oracle, tracer, cornell):
