@@ -11,7 +11,7 @@ segments whose hit is taken from the per-pixel primary-ray memo (no traversal)
 are counted too and `Mrays_traversed/s` is reported beside the headline.
 
 The timed region renders K frames with rt_render_frames: frames are sampled in
-batches (default 16 per launch) by ONE persistent launch over (frame, tile) work
+batches (default 32 per launch) by ONE persistent launch over (frame, tile) work
 items and blended in frame order by a dense second kernel -- bit-identical to K
 single-frame launches (tests/test_gpu_frames.py).  The single-frame
 (un-overlapped) latency and the first frame after a camera change are measured
@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU-staged rehearsal on one GPU)")
-    ap.add_argument("--batch", type=int, default=16, help="frames per launch of rt_render_frames (1 = one launch per frame)")
+    ap.add_argument("--batch", type=int, default=32, help="frames per launch of rt_render_frames (1..32; 1 = one launch per frame)")
     ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning; default: library default)")
     ap.add_argument("--blocks", type=int, default=None, help="persistent grid size (tuning)")
     args = ap.parse_args()
@@ -113,7 +113,7 @@ def main():
     arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
     tracer = rt.RayTracer(device=device, max_width=W, max_height=H)
     tracer.load_scene(arrays)
-    tracer.set_option("batch_frames", max(1, args.batch))
+    tracer.set_option("batch_frames", max(1, min(32, args.batch)))
     if args.variant is not None:
         tracer.set_option("kernel_variant", args.variant)
     if args.blocks is not None:
