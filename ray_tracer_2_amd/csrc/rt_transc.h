@@ -210,10 +210,10 @@ RT_HD float cos_kernel(float x) {
     float z = x * x;
     float r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
     uint32_t ix = f2u(x) & 0x7fffffffu;
-    if (ix < 0x3e99999au) {  // |x| < 0.3
-        return 1.0f - (0.5f * z - z * r);
-    }
-    float qx = (ix > 0x3f480000u) ? 0.28125f : u2f(ix - 0x01000000u);  // ~|x|/4
+    // |x| < 0.3: 1 - (z/2 - z r); above: the same with qx ~ |x|/4 moved from one term to the other.  One
+    // expression for both (qx = 0 gives the first form bit for bit: z/2 - 0 and 1 - 0 are exact), so that a wave
+    // whose lanes fall on both sides does not execute two paths.
+    float qx = (ix < 0x3e99999au) ? 0.0f : ((ix > 0x3f480000u) ? 0.28125f : u2f(ix - 0x01000000u));  // ~|x|/4
     float hz = 0.5f * z - qx;
     float a = 1.0f - qx;
     return a - (hz - z * r);
@@ -247,7 +247,9 @@ RT_HD TrigRed trig_reduce(float x) {
 RT_HD float sin_(float x) {
     uint32_t ax = f2u(x) & 0x7fffffffu;
     if (ax >= 0x4f000000u) return u2f(0x7fc00000u);  // |x| >= 2^31, inf, NaN -> NaN
-    if (ax < 0x3f490fdau) return sin_kernel(x);  // |x| < pi/4
+    // (no shortcut for |x| < pi/4: there n = +-0, r = fma(-+0, P1, x) = x and q = 0, so the general path returns
+    // sin_kernel(x) itself -- checked over every float below pi/4 -- and a wave whose lanes straddle pi/4 would
+    // execute both paths)
     TrigRed t = trig_reduce(x);
     float s = sin_kernel(t.r), c = cos_kernel(t.r);
     float v = (t.q & 1) ? c : s;
@@ -257,8 +259,7 @@ RT_HD float sin_(float x) {
 RT_HD float cos_(float x) {
     uint32_t ax = f2u(x) & 0x7fffffffu;
     if (ax >= 0x4f000000u) return u2f(0x7fc00000u);
-    if (ax < 0x3f490fdau) return cos_kernel(x);
-    TrigRed t = trig_reduce(x);
+    TrigRed t = trig_reduce(x);  // (|x| < pi/4: n = 0, r = x, the result is cos_kernel(x); see sin_)
     float s = sin_kernel(t.r), c = cos_kernel(t.r);
     float v = (t.q & 1) ? s : c;
     return ((t.q + 1) & 2) ? -v : v;
