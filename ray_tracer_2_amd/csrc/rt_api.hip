@@ -57,6 +57,7 @@ struct rt_handle {
     // frame batches (rt_render_frames): scratch images of the frames in flight
     float4* batch_scratch = nullptr;
     size_t batch_scratch_texels = 0;
+    int batch_tile_major = 1;  // option "batch_tile_major": (tile, frame) instead of (frame, tile) order of a batch's work items
     int batch_frames_opt = 16;  // option "batch_frames": frames per launch of rt_render_frames (1..RT_MAX_BATCH_FRAMES)
     // rt_render_multi: what the root's stream has to finish before this handle's image may be overwritten
     hipEvent_t multi_copied = nullptr;  // (owned by the root handle, below)
@@ -826,6 +827,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "multi_rccl") {
         if (value < 0 || value > 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "multi_rccl must be 0 (peer copies), 1 (RCCL between distinct devices) or 2 (RCCL always)");
         h->multi_rccl = value;
+    } else if (n == "batch_tile_major") {
+        h->batch_tile_major = value ? 1 : 0;
     } else if (n == "batch_frames") {
         if (value < 1 || value > (int)RT_MAX_BATCH_FRAMES) return fail(h, RT_ERR_INVALID_ARGUMENT, "batch_frames must be 1..32");
         h->batch_frames_opt = value;
@@ -882,6 +885,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         }
         a.batch_frames = n_batch;
         a.batch_stride = need_texels;
+        a.batch_tile_major = (uint32_t)h->batch_tile_major;
     }
     for (int k = 0; k < 3; ++k) {  // see pixel_cache_begin: the same IEEE operations, unfused
         volatile float rz = h->camera.cam_to_world[0][k] * 0.0f, uz = h->camera.cam_to_world[1][k] * 0.0f;

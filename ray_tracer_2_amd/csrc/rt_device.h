@@ -169,6 +169,7 @@ struct RenderArgs {
     // unblended to image + k * batch_stride and rt_blend_frames_kernel applies wgsl:154-161 in frame
     // order afterwards.  0 = a plain one-frame launch that blends in place.
     uint32_t batch_frames;
+    uint32_t batch_tile_major;  // 1 => work items in (tile, frame) order instead of (frame, tile)
     unsigned long long batch_stride;  // texels between the scratch frames
     // LDS-staged top of a big mesh's BVH (scenes read from global memory): wide records top_base ..
     // top_base + top_count - 1 -- the first levels of the biggest mesh, numbered breadth-first at upload

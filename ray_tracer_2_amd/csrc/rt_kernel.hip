@@ -1496,8 +1496,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                 } else {
                     pool_frame = 0u;
                     if (a.batch_frames != 0u) {
-                        pool_frame = t / n_tiles;
-                        t -= pool_frame * n_tiles;
+                        if (a.batch_tile_major != 0u) {  // (tile, frame) order: a tile's frames back to back
+                            const uint32_t tt = t / a.batch_frames;
+                            pool_frame = t - tt * a.batch_frames;
+                            t = tt;
+                        } else {
+                            pool_frame = t / n_tiles;
+                            t -= pool_frame * n_tiles;
+                        }
                     }
                     if (a.tile_order) t = a.tile_order[t];  // heaviest tiles first (an earlier frame's cost)
                     pool_base = t * 64u;

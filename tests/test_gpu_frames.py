@@ -55,7 +55,7 @@ def test_render_frames_against_the_oracle(rt, oracle, tracer, cornell):
     assert tracer.stats().segments == segs
 
 
-@pytest.mark.parametrize("kw", [dict(lds_scene=0), dict(pixel_cache=0), dict(pixel_cache=2), dict(tile_feedback=0)])
+@pytest.mark.parametrize("kw", [dict(lds_scene=0), dict(pixel_cache=0), dict(pixel_cache=2), dict(tile_feedback=0), dict(batch_tile_major=0)])
 def test_render_frames_under_every_kernel_option(rt, tracer, cornell, kw):
     w, h = 160, 90
     tracer.load_scene(cornell)
@@ -69,7 +69,7 @@ def test_render_frames_under_every_kernel_option(rt, tracer, cornell, kw):
         tracer.render_frames(rt.make_params(w, h, 4, 8, skybox=1, frames=0), 12)
         got = tracer.read_image(w, h)
     finally:
-        tracer.set_option(k, {"lds_scene": 1, "pixel_cache": 1, "tile_feedback": 1}[k])
+        tracer.set_option(k, {"lds_scene": 1, "pixel_cache": 1, "tile_feedback": 1, "batch_tile_major": 1}[k])
         tracer.set_option("batch_frames", 16)
     assert np.array_equal(bits(got), bits(want))
 
