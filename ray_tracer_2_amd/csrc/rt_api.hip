@@ -920,6 +920,8 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.stack_entries = h->stack_entries;
     a.tlas_entries = h->tlas_entries;
     a.stack_wide = (h->stack_must_wide || (h->force_stack_wide < 0 ? h->stack_wide : h->force_stack_wide != 0)) ? 1u : 0u;
+    // (the global-memory kernels park a pending mesh hit of 7 dwords in the stack column, intersect_scene)
+    if (!a.lds_scene && a.stack_entries < (a.stack_wide ? 4u : 7u)) a.stack_entries = a.stack_wide ? 4u : 7u;
     a.n_items = h->n_items;
     a.strip_rank = rank;
     a.strip_world = world;

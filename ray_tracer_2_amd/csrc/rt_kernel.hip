@@ -708,16 +708,63 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         world_hit<LDS>(a, a.lay.mesh_off + i * MESH_REC_BYTES + 64u, lo, ld, ro, b.t, whp, wdst);
         isect_offer(I, i, b, whp, wdst);
     };
+    // Deferred offers.  The meshes every lane visits together (root-leaf and two-leaf items) are hit by a few lanes
+    // each, and mostly by different lanes: offering each hit at once costs a sparsely populated pass of world_hit
+    // per mesh.  A lane therefore keeps ONE hit pending and offers it when it gets another one (rare: a ray seldom
+    // hits two of these meshes), when the local space changes, or at the end -- where most lanes offer together.
+    // The offers are order-free (isect_offer breaks ties by mesh index), so nothing changes but the number of passes.
+    // Where the pending hit lives: in registers in the LDS-scene kernels (their LDS pipe is the busy one: parked in
+    // LDS it cost 1 % instead of saving 1.2 %), in the lane's BVH stack column in the global-memory kernels (7
+    // dwords, RenderArgs::stack_entries is sized for it; nobody uses the column while these meshes are visited, and
+    // the hit is offered before anything walks a BVH -- there the registers are the scarce resource: -1.6 %).
+    MeshBest pend;
+    pend.t = INF;
+    pend.tri = 0xffffffffu;
+    pend.u = pend.v = pend.w = pend.det = 0.0f;
+    uint32_t pend_mesh = 0xffffffffu;
+    bool have_pending = false;
+    auto flush_pending = [&]() {
+        if constexpr (LDS) {
+            if (pend_mesh != 0xffffffffu) {
+                accept_mesh_hit(pend_mesh, pend);
+                pend_mesh = 0xffffffffu;
+            }
+        } else {
+            if (have_pending) {
+                MeshBest p;
+                p.t = __uint_as_float(stack[0]); p.u = __uint_as_float(stack[64]); p.v = __uint_as_float(stack[128]);
+                p.w = __uint_as_float(stack[192]); p.det = __uint_as_float(stack[256]); p.tri = stack[320];
+                accept_mesh_hit(stack[384], p);
+                have_pending = false;
+            }
+        }
+    };
+    auto offer_later = [&](uint32_t i, const MeshBest& b) {
+        flush_pending();
+        if constexpr (LDS) {
+            pend = b;
+            pend_mesh = i;
+        } else {
+            stack[0] = __float_as_uint(b.t); stack[64] = __float_as_uint(b.u); stack[128] = __float_as_uint(b.v);
+            stack[192] = __float_as_uint(b.w); stack[256] = __float_as_uint(b.det); stack[320] = b.tri;
+            stack[384] = i;
+            have_pending = true;
+        }
+    };
     auto visit_mesh = [&](uint32_t i, float4 hdr) {
         const uint32_t flags = fbits(hdr.x);
         MeshBest b;
         b.t = INF;
         b.tri = 0xffffffffu;
         b.u = b.v = b.w = b.det = 0.0f;
+        if (!TLAS && !LDS && fbits(hdr.z) == 0u) flush_pending();  // (a BVH walk uses the stack column)
         traverse_mesh<LDS, STATS>(a, fbits(hdr.y), fbits(hdr.z),
                                   (flags & DMESH_GLASS) == 0, (flags & DMESH_DEEP) != 0, lo, ld, inv, stack, b,
                                   node_tests, tri_tests);
-        if (b.tri != 0xffffffffu) accept_mesh_hit(i, b);
+        if (b.tri != 0xffffffffu) {
+            if (!TLAS && fbits(hdr.z) != 0u) offer_later(i, b);  // root leaf: the wave visits it in step
+            else accept_mesh_hit(i, b);
+        }
     };
     for (uint32_t it = 0; it < a.n_items; ++it) {
         const float4 item = ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES);
@@ -725,6 +772,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         const uint32_t kind = __builtin_amdgcn_readfirstlane(fbits(item.x));
         const uint32_t ia = __builtin_amdgcn_readfirstlane(fbits(item.y));
         if (kind & ITEM_NEW_XFORM) {
+            if constexpr (!TLAS) flush_pending();  // (a pending hit belongs to the old local space)
             DIAG(3);
             TIC(t3);
             // meshes with bit-identical world_to_model share the local ray (same inputs, same bits)
@@ -741,6 +789,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             TOC(t3, 3);
         }
         if constexpr (!TLAS) if (kind & ITEM_FOREST) {
+            if constexpr (!LDS) flush_pending();  // (the forest walk uses the stack column)
             traverse_forest<LDS, STATS>(a, ia, __builtin_amdgcn_readfirstlane(fbits(item.w)), lo, ld, inv, stack,
                                         accept_mesh_hit, node_tests, tri_tests);
             continue;
@@ -754,7 +803,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                 b.u = b.v = b.w = b.det = 0.0f;
                 traverse_flat2<LDS, STATS>(a, __builtin_amdgcn_readfirstlane(fbits(hdr.y)), (fbits(hdr.x) & DMESH_GLASS) == 0, lo, ld, inv,
                                            b, node_tests, tri_tests);
-                if (b.tri != 0xffffffffu) accept_mesh_hit(ia, b);
+                if (b.tri != 0xffffffffu) offer_later(ia, b);
             } else {
                 visit_mesh(ia, hdr);
             }
@@ -820,6 +869,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             }
         }
     }
+    if constexpr (!TLAS) flush_pending();
     return isect_finish<LDS>(a, I, ro, rd);
 }
 
