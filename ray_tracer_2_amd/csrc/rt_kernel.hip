@@ -592,18 +592,30 @@ struct Isect {
     bool any = false;
     float s_dst = 0.0f;     // sphere winner: distance, inside flag
     bool s_inside = false;
-    MeshBest win{};         // mesh winner: its triangle data and world hit point
+    // mesh winner: its triangle, barycentrics and world hit point.  Kept compact (4 registers instead of MeshBest's
+    // 6): w is (1 - u) - v again (the operations of wgsl:280) and of the determinant only the sign is used later
+    // (wgsl:284-285; it cannot be zero, wgsl:268) -- it rides in the triangle index's top bit.
+    float win_u = 0.0f, win_v = 0.0f;
+    uint32_t win_tri = 0;   // | 0x80000000: determinant negative
     f3 win_point{0, 0, 0};
 };
 
 // closest-hit update of wgsl:383-391; equal distances go to the lower mesh index, which is
 // what the shader's in-order loop with its strict `<` yields
-DEV void isect_offer(Isect& I, uint32_t i, const MeshBest& b, f3 whp, float wdst) {
+struct CompactHit {  // what the mesh loop keeps of a mesh's closest triangle hit (see Isect)
+    float t, u, v;
+    uint32_t tri;  // | 0x80000000: determinant negative
+};
+DEV CompactHit compact(const MeshBest& b) { return CompactHit{b.t, b.u, b.v, b.tri | (b.det < 0.0f ? 0x80000000u : 0u)}; }
+
+DEV void isect_offer(Isect& I, uint32_t i, const CompactHit& b, f3 whp, float wdst) {
     if (wdst < I.closest || (wdst == I.closest && I.any && I.object >= 0 && (int)i < I.object)) {
         I.closest = wdst;
         I.any = true;
         I.object = (int)i;
-        I.win = b;
+        I.win_u = b.u;
+        I.win_v = b.v;
+        I.win_tri = b.tri;
         I.win_point = whp;
     }
 }
@@ -656,19 +668,21 @@ DEV Hit isect_finish(const RenderArgs& a, const Isect& I, f3 ro, f3 rd) {
         DIAG(11);
         if (I.object >= 0) {
             const uint32_t mo = a.lay.mesh_off + (uint32_t)I.object * MESH_REC_BYTES;
-            const uint32_t so = a.lay.shade_off + I.win.tri * TRI_SHADE_BYTES;
+            const uint32_t so = a.lay.shade_off + (I.win_tri & 0x7fffffffu) * TRI_SHADE_BYTES;
+            const bool det_negative = (I.win_tri & 0x80000000u) != 0u;
+            const float wu = I.win_u, wv = I.win_v, ww = (1.0f - wu) - wv;
             const float4 s0 = ld4<LDS>(a, so), s1 = ld4<LDS>(a, so + 16), s2 = ld4<LDS>(a, so + 32),
                          s3 = ld4<LDS>(a, so + 48);
             f3 n1{s0.x, s0.y, s0.z}, n2{s1.x, s1.y, s1.z}, n3{s2.x, s2.y, s2.z};
-            f3 ln = normalize3((n1 * I.win.w + n2 * I.win.u) + n3 * I.win.v) * sign_(I.win.det);
+            f3 ln = normalize3((n1 * ww + n2 * wu) + n3 * wv) * (det_negative ? -1.0f : 1.0f);
             const float4 c0 = ld4<LDS>(a, mo + 64), c1 = ld4<LDS>(a, mo + 80), c2 = ld4<LDS>(a, mo + 96),
                          c3 = ld4<LDS>(a, mo + 112);
             h.normal = normalize3(mat_cols_xyz(c0, c1, c2, c3, ln, 0.0f));
-            h.backface = I.win.det < 0.0f;
+            h.backface = det_negative;
             h.point = I.win_point;
             // uv = (uv1 * w + uv2 * u) + uv3 * v, uv1 = (u10,u11), uv2 = (u20,u21), uv3 = (u30,u31)
-            h.u = (s0.w * I.win.w + s2.w * I.win.u) + s3.y * I.win.v;
-            h.v = (s1.w * I.win.w + s3.x * I.win.u) + s3.z * I.win.v;
+            h.u = (s0.w * ww + s2.w * wu) + s3.y * wv;
+            h.v = (s1.w * ww + s3.x * wu) + s3.z * wv;
             h.mat_off = a.lay.mat_off + (uint32_t)I.object * MATERIAL_BYTES;
         } else {
             const uint32_t si = (uint32_t)(-I.object - 1);
@@ -701,40 +715,38 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
     // meshes (wgsl:369-393), as items: single meshes and top-level trees over mesh root boxes
     f3 lo{0, 0, 0}, ld{0, 0, 0}, inv{0, 0, 0};
     bool cull_ok = false;
-    auto accept_mesh_hit = [&](uint32_t i, const MeshBest& b) {
+    auto accept_hit = [&](uint32_t i, const CompactHit& b) {
         DIAG(10);
         f3 whp;
         float wdst;
         world_hit<LDS>(a, a.lay.mesh_off + i * MESH_REC_BYTES + 64u, lo, ld, ro, b.t, whp, wdst);
         isect_offer(I, i, b, whp, wdst);
     };
+    auto accept_mesh_hit = [&](uint32_t i, const MeshBest& b) { accept_hit(i, compact(b)); };
     // Deferred offers.  The meshes every lane visits together (root-leaf and two-leaf items) are hit by a few lanes
     // each, and mostly by different lanes: offering each hit at once costs a sparsely populated pass of world_hit
     // per mesh.  A lane therefore keeps ONE hit pending and offers it when it gets another one (rare: a ray seldom
     // hits two of these meshes), when the local space changes, or at the end -- where most lanes offer together.
     // The offers are order-free (isect_offer breaks ties by mesh index), so nothing changes but the number of passes.
     // Where the pending hit lives: in registers in the LDS-scene kernels (their LDS pipe is the busy one: parked in
-    // LDS it cost 1 % instead of saving 1.2 %), in the lane's BVH stack column in the global-memory kernels (7
+    // LDS it cost 1 % instead of saving 1.2 %), in the lane's BVH stack column in the global-memory kernels (5
     // dwords, RenderArgs::stack_entries is sized for it; nobody uses the column while these meshes are visited, and
     // the hit is offered before anything walks a BVH -- there the registers are the scarce resource: -1.6 %).
-    MeshBest pend;
-    pend.t = INF;
-    pend.tri = 0xffffffffu;
-    pend.u = pend.v = pend.w = pend.det = 0.0f;
+    CompactHit pend{INF, 0.0f, 0.0f, 0u};
     uint32_t pend_mesh = 0xffffffffu;
     bool have_pending = false;
     auto flush_pending = [&]() {
         if constexpr (LDS) {
             if (pend_mesh != 0xffffffffu) {
-                accept_mesh_hit(pend_mesh, pend);
+                accept_hit(pend_mesh, pend);
                 pend_mesh = 0xffffffffu;
             }
         } else {
             if (have_pending) {
-                MeshBest p;
+                CompactHit p;
                 p.t = __uint_as_float(stack[0]); p.u = __uint_as_float(stack[64]); p.v = __uint_as_float(stack[128]);
-                p.w = __uint_as_float(stack[192]); p.det = __uint_as_float(stack[256]); p.tri = stack[320];
-                accept_mesh_hit(stack[384], p);
+                p.tri = stack[192];
+                accept_hit(stack[256], p);
                 have_pending = false;
             }
         }
@@ -742,12 +754,12 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
     auto offer_later = [&](uint32_t i, const MeshBest& b) {
         flush_pending();
         if constexpr (LDS) {
-            pend = b;
+            pend = compact(b);
             pend_mesh = i;
         } else {
             stack[0] = __float_as_uint(b.t); stack[64] = __float_as_uint(b.u); stack[128] = __float_as_uint(b.v);
-            stack[192] = __float_as_uint(b.w); stack[256] = __float_as_uint(b.det); stack[320] = b.tri;
-            stack[384] = i;
+            stack[192] = b.tri | (b.det < 0.0f ? 0x80000000u : 0u);
+            stack[256] = i;
             have_pending = true;
         }
     };
@@ -757,7 +769,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         b.t = INF;
         b.tri = 0xffffffffu;
         b.u = b.v = b.w = b.det = 0.0f;
-        if (!TLAS && !LDS && fbits(hdr.z) == 0u) flush_pending();  // (a BVH walk uses the stack column)
+        if (!TLAS && fbits(hdr.z) == 0u) flush_pending();  // (a BVH walk uses the stack column / is where the register pressure peaks)
         traverse_mesh<LDS, STATS>(a, fbits(hdr.y), fbits(hdr.z),
                                   (flags & DMESH_GLASS) == 0, (flags & DMESH_DEEP) != 0, lo, ld, inv, stack, b,
                                   node_tests, tri_tests);
@@ -789,7 +801,10 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             TOC(t3, 3);
         }
         if constexpr (!TLAS) if (kind & ITEM_FOREST) {
-            if constexpr (!LDS) flush_pending();  // (the forest walk uses the stack column)
+            // (the forest walk uses the stack column; and in the LDS-scene kernels a pending hit held across the
+            // walk, where the register pressure peaks, was 7 more spilled dwords per lane: 95 MB of scratch write-back
+            // per frame)
+            flush_pending();
             traverse_forest<LDS, STATS>(a, ia, __builtin_amdgcn_readfirstlane(fbits(item.w)), lo, ld, inv, stack,
                                         accept_mesh_hit, node_tests, tri_tests);
             continue;
