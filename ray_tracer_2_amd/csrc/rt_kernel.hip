@@ -239,8 +239,10 @@ DEV f3 mat_cols_xyz(float4 c0, float4 c1, float4 c2, float4 c3, f3 v, float w) {
 
 // ---- intersection ---------------------------------------------------------
 struct MeshBest {  // closest triangle hit inside the mesh being traversed
-    float t, u, v, w, det;
-    uint32_t tri;  // mesh-local triangle index
+    // (w and the determinant are not kept: w is (1 - u) - v again where it is needed -- the operations of wgsl:280 --
+    // and of the determinant only the sign is used after the test, wgsl:284-285; it cannot be zero, wgsl:268)
+    float t, u, v;
+    uint32_t tri;  // triangle index (absolute) | 0x80000000 when the determinant is negative; 0xffffffff: no hit
 };
 
 // wgsl:258-290 against the pre-laid-out record (rt_device.h): edge_ab, edge_ac
@@ -270,9 +272,7 @@ DEV void tri_test(f3 lo, f3 ld, float4 q0, float4 q1, float4 q2, bool cull, uint
             b.t = dst;
             b.u = u;
             b.v = v;
-            b.w = w;
-            b.det = det;
-            b.tri = idx;
+            b.tri = idx | (det < 0.0f ? 0x80000000u : 0u);
         }
     }
 }
@@ -497,7 +497,7 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
     MeshBest b;
     b.t = INF;
     b.tri = 0xffffffffu;
-    b.u = b.v = b.w = b.det = 0.0f;
+    b.u = b.v = 0.0f;
     for (;;) {
         TIC(t8);
         if (!have) {
@@ -606,7 +606,7 @@ struct CompactHit {  // what the mesh loop keeps of a mesh's closest triangle hi
     float t, u, v;
     uint32_t tri;  // | 0x80000000: determinant negative
 };
-DEV CompactHit compact(const MeshBest& b) { return CompactHit{b.t, b.u, b.v, b.tri | (b.det < 0.0f ? 0x80000000u : 0u)}; }
+DEV CompactHit compact(const MeshBest& b) { return CompactHit{b.t, b.u, b.v, b.tri}; }
 
 DEV void isect_offer(Isect& I, uint32_t i, const CompactHit& b, f3 whp, float wdst) {
     if (wdst < I.closest || (wdst == I.closest && I.any && I.object >= 0 && (int)i < I.object)) {
@@ -758,7 +758,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             pend_mesh = i;
         } else {
             stack[0] = __float_as_uint(b.t); stack[64] = __float_as_uint(b.u); stack[128] = __float_as_uint(b.v);
-            stack[192] = b.tri | (b.det < 0.0f ? 0x80000000u : 0u);
+            stack[192] = b.tri;
             stack[256] = i;
             have_pending = true;
         }
@@ -768,7 +768,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         MeshBest b;
         b.t = INF;
         b.tri = 0xffffffffu;
-        b.u = b.v = b.w = b.det = 0.0f;
+        b.u = b.v = 0.0f;
         if (!TLAS && fbits(hdr.z) == 0u) flush_pending();  // (a BVH walk uses the stack column / is where the register pressure peaks)
         traverse_mesh<LDS, STATS>(a, fbits(hdr.y), fbits(hdr.z),
                                   (flags & DMESH_GLASS) == 0, (flags & DMESH_DEEP) != 0, lo, ld, inv, stack, b,
@@ -815,7 +815,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                 MeshBest b;
                 b.t = INF;
                 b.tri = 0xffffffffu;
-                b.u = b.v = b.w = b.det = 0.0f;
+                b.u = b.v = 0.0f;
                 traverse_flat2<LDS, STATS>(a, __builtin_amdgcn_readfirstlane(fbits(hdr.y)), (fbits(hdr.x) & DMESH_GLASS) == 0, lo, ld, inv,
                                            b, node_tests, tri_tests);
                 if (b.tri != 0xffffffffu) offer_later(ia, b);
