@@ -55,6 +55,28 @@ def test_render_frames_against_the_oracle(rt, oracle, tracer, cornell):
     assert tracer.stats().segments == segs
 
 
+def test_render_frames_with_the_stats_counters(rt, oracle, tracer, cornell):
+    """The counter kernels (wgsl:307,322 stats) in batch mode: the sums over the frames equal the oracle's."""
+    w, h, n = 80, 48, 4
+    tracer.load_scene(cornell)
+    ref = np.zeros((h, w, 4), np.float32)
+    seg = nt = tt = 0
+    for f in range(n):
+        ref, st = oracle.render(rt.make_params(w, h, 3, 2, skybox=1, frames=f), cornell, image=ref)
+        seg, nt, tt = seg + st.segments, nt + st.node_tests, tt + st.triangle_tests
+    tracer.set_counters(True)
+    try:
+        tracer.reset_timing()
+        tracer.render_frames(rt.make_params(w, h, 3, 2, skybox=1, frames=0), n)
+        got = tracer.read_image(w, h)
+        s = tracer.stats()
+    finally:
+        tracer.set_counters(False)
+    assert np.array_equal(bits(got), bits(ref))
+    assert (s.segments, s.node_tests, s.triangle_tests) == (seg, nt, tt)
+    assert s.segments_reused == 0   # the counter kernels re-intersect memoised rays so that the counters stay the shader's
+
+
 @pytest.mark.parametrize("kw", [dict(lds_scene=0), dict(pixel_cache=0), dict(pixel_cache=2), dict(tile_feedback=0), dict(batch_tile_major=0)])
 def test_render_frames_under_every_kernel_option(rt, tracer, cornell, kw):
     w, h = 160, 90
