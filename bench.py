@@ -96,6 +96,7 @@ def main():
 
     import torch
     import ray_tracer_2_amd as rt
+    from ray_tracer_2_amd import parallel
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
@@ -151,15 +152,16 @@ def main():
             p.frames = f0 + done
             tracer.render_strips_frames(p, nb, rank, world)
             if args.backend == "nccl":
-                dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+                # one gather over RCCL + de-interleave on the root's device (ray_tracer_2_amd/parallel.py)
+                parallel.gather_frame(dist, local, W, H, rank, world, gathered=gathered,
+                                      assemble_fn=lambda g, w, h, n: assembler.assemble_strips(g.data_ptr(), w, h, n))
             else:  # rehearsal: stage through the host
                 host = local.cpu()
                 parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, parts, dst=0)
                 if rank == 0:
                     gathered.copy_(torch.stack(parts))
-            if rank == 0:
-                assembler.assemble_strips(gathered.data_ptr(), W, H, world)
+                    assembler.assemble_strips(gathered.data_ptr(), W, H, world)
             done += nb
 
     def fence():

@@ -54,14 +54,17 @@ def assemble(gathered, width, height, world):
     return out
 
 
-def gather_frame(dist, local, width, height, rank, world, assemble_fn=None):
-    """One collective per frame: every rank contributes its padded local buffer,
-    rank 0 receives [world, pad_texels, 4] and assembles the frame.
-    `local` is a torch tensor of shape [pad_texels, 4] (device or CPU)."""
+def gather_frame(dist, local, width, height, rank, world, assemble_fn=None, gathered=None):
+    """One collective per displayed frame (or per batch of accumulated frames): every rank contributes
+    its padded local buffer, rank 0 receives [world, pad_texels, 4] and assembles the frame.
+    `local` is a torch tensor of shape [pad_texels, 4] (device or CPU); `gathered` an optional
+    preallocated receive buffer on rank 0; `assemble_fn(gathered, width, height, world)` replaces the
+    reference assembly (bench.py passes rt_assemble_strips on the device)."""
     import torch
     pad = pad_texels(width, height, world)
     assert local.shape == (pad, 4)
-    gathered = torch.empty((world, pad, 4), dtype=local.dtype, device=local.device) if rank == 0 else None
+    if rank == 0 and gathered is None:
+        gathered = torch.empty((world, pad, 4), dtype=local.dtype, device=local.device)
     dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
     if rank != 0:
         return None

@@ -35,6 +35,8 @@ def _worker(rank, world, port, width, height, out_path):
     arrays = rt.SceneArrays.load(os.path.join(GOLDEN, "cornell_scene.npz"))
     pad = parallel.pad_texels(width, height, world)
     local = torch.zeros((pad, 4), dtype=torch.float32)
+    # frame 1 goes through the form bench.py uses: a preallocated receive buffer and a caller-supplied assembly
+    gathered = torch.empty((world, pad, 4), dtype=torch.float32) if rank == 0 else None
     frame = None
     full = np.zeros((height, width, 4), np.float32)       # this rank's scratch full-frame target
     for f in range(2):                                     # frame 1 exercises per-rank accumulation
@@ -43,7 +45,11 @@ def _worker(rank, world, port, width, height, out_path):
         oracle.render(p, arrays, image=full, rows=np.array(rows, np.uint32), threads=2)
         buf = local.numpy().reshape(-1, width, 4)
         buf[:len(rows)] = full[rows]                       # compact strip-major layout (8 rows per strip)
-        frame = parallel.gather_frame(dist, local, width, height, rank, world)
+        if f == 0:
+            frame = parallel.gather_frame(dist, local, width, height, rank, world)
+        else:
+            frame = parallel.gather_frame(dist, local, width, height, rank, world, gathered=gathered,
+                                          assemble_fn=lambda g, w, h, n: parallel.assemble(g, w, h, n))
     if rank == 0:
         np.save(out_path, frame.numpy())
     dist.barrier()
