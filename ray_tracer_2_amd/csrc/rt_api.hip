@@ -57,7 +57,6 @@ struct rt_handle {
     // frame batches (rt_render_frames): scratch images of the frames in flight
     float4* batch_scratch = nullptr;
     size_t batch_scratch_texels = 0;
-    int batch_stride_pad = 8 * 17 * 3;  // option "batch_stride_pad": texels between the scratch frames beyond the frame size (51 lines of 128 B)
     int batch_tile_major = 1;  // option "batch_tile_major": (tile, frame) instead of (frame, tile) order of a batch's work items
     int batch_frames_opt = 16;  // option "batch_frames": frames per launch of rt_render_frames (1..RT_MAX_BATCH_FRAMES)
     // rt_render_multi: what the root's stream has to finish before this handle's image may be overwritten
@@ -828,15 +827,6 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "multi_rccl") {
         if (value < 0 || value > 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "multi_rccl must be 0 (peer copies), 1 (RCCL between distinct devices) or 2 (RCCL always)");
         h->multi_rccl = value;
-    } else if (n == "batch_stride_pad") {
-        if (value < 0 || value > (1 << 20)) return fail(h, RT_ERR_INVALID_ARGUMENT, "batch_stride_pad must be 0..2^20 texels");
-        if (value != h->batch_stride_pad) {  // the scratch is laid out anew
-            HIP_TRY(h, hipSetDevice(h->device));
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            free_dev(h->batch_scratch);
-            h->batch_scratch_texels = 0;
-        }
-        h->batch_stride_pad = value;
     } else if (n == "batch_tile_major") {
         h->batch_tile_major = value ? 1 : 0;
     } else if (n == "batch_frames") {
@@ -884,11 +874,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.camera = h->camera;
     if (n_batch) {
         if (n_batch > RT_MAX_BATCH_FRAMES) return fail(h, RT_ERR_INVALID_ARGUMENT, "batch too large");
-        // Scratch frames are spaced by the frame size plus an odd number of 128-byte lines: with a stride that is a
-        // multiple of 8 KiB (1080p: 2^13 x 4050 B) the same tile's texels of all frames of the batch fall into the same
-        // L2 sets, partially written sectors are evicted before their other texels arrive, and every 16-byte texel
-        // store reaches HBM on its own (profiles/r02d_summary.txt: 133 instead of 40 MB of writes per frame).
-        const uint64_t scratch_stride = need_texels + (uint64_t)h->batch_stride_pad;
+        const uint64_t scratch_stride = need_texels;
         if (h->batch_scratch_texels < scratch_stride * n_batch) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             free_dev(h->batch_scratch);
@@ -1080,7 +1066,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         b.image = h->image;
         b.scratch = h->batch_scratch;
         b.texels = need_texels;
-        b.stride = need_texels + (uint64_t)h->batch_stride_pad;
+        b.stride = need_texels;
         b.n = n_batch;
         b.frames0 = params->frames;
         for (uint32_t k = 0; k < n_batch; ++k) {  // wgsl:157-158 per frame: the same two IEEE operations
