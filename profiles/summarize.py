@@ -24,10 +24,10 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 
 def rows(pat):
-    out = []
-    for f in glob.glob(pat):
-        out += list(csv.DictReader(open(f)))
-    return out
+    """Rows of the NEWEST file that matches (gpurun merges a call's outputs into gpurun_out/, so a tag that was
+    profiled twice holds both runs' files: only the last run counts)."""
+    files = sorted(glob.glob(pat), key=os.path.getmtime)
+    return list(csv.DictReader(open(files[-1]))) if files else []
 
 
 def main():
