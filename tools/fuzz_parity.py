@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Stress version of tests/test_gpu_scenes.py::test_random_scenes: N seeded random scenes, GPU (both kernel
-variants, with and without counters) against the CPU oracle, bit for bit.  usage: fuzz_parity.py [first] [count]"""
+variants, with and without counters, one launch per frame; and three accumulating frames as one batch of
+rt_render_frames) against the CPU oracle, bit for bit.  usage: fuzz_parity.py [first] [count]"""
 import os
 import sys
 
@@ -37,6 +38,18 @@ for seed in range(first, first + count):
                 bad += 1
                 print(f"MISMATCH seed {seed} variant {variant} counters {counters}: {int((gpu.view(np.uint32) != ref.view(np.uint32)).sum())} words differ")
     tr.set_counters(False)
+    tr.set_option("kernel_variant", -1)
+    # three accumulating frames: sequentially on the oracle, as one overlapped batch on the GPU
+    acc = np.zeros((h, w, 4), np.float32)
+    for f in range(3):
+        p.frames = f
+        acc, _ = oracle.render(p, arrays, image=acc)
+    p.frames = 0
+    tr.write_image(np.zeros((h, w, 4), np.float32))
+    tr.render_frames(p, 3)
+    if not np.array_equal(tr.read_image(w, h).view(np.uint32), acc.view(np.uint32)):
+        bad += 1
+        print(f"MISMATCH seed {seed} rt_render_frames")
     if (seed - first) % 50 == 49:
         print(f"... {seed - first + 1} scenes, {bad} mismatches", flush=True)
 print(f"{count} scenes, {bad} mismatches")
