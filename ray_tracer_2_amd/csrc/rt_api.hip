@@ -1225,7 +1225,10 @@ static int render_multi_impl(rt_handle** per_gpu, int n_gpus, const rt_params* p
             rt_handle* h = per_gpu[r];
             const uint64_t n = rank_texels(r);
             if (n == 0) continue;
+            // (each call with its communicator's device current: older RCCL releases require it in one-thread use)
+            HIP_TRY(h, hipSetDevice(h->device));
             NCCL_TRY(root, g_rccl.Send(h->image, n * 4, ncclFloat, 0, (ncclComm_t)root->multi_comms[r], h->stream));
+            HIP_TRY(root, hipSetDevice(root->device));
             NCCL_TRY(root, g_rccl.Recv(root->multi_gathered + (size_t)r * pad, n * 4, ncclFloat, r, (ncclComm_t)root->multi_comms[0], root->stream));
         }
         NCCL_TRY(root, g_rccl.GroupEnd());
