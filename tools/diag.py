@@ -55,6 +55,9 @@ def main():
         g = os.path.join(ROOT, "tests", "golden")
         arrays = rt.SceneArrays.from_scene(scenes.cornell_dragon(scenes.load_raw_meshes(os.path.join(g, "cornell_raw.npz")),
                                                                  scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")), 3))
+    elif os.environ.get("DIAG_SCENE") == "sponza":
+        from ray_tracer_2_amd import scenes
+        arrays = rt.SceneArrays.from_scene(scenes.sponza_standin(200))
     else:
         arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
     tr = rt.RayTracer(0, W, H)
