@@ -497,7 +497,9 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         };
         struct Box { float lo[3], hi[3]; };
         auto asf2 = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
-        // recursive median split over root-box centroids; returns the child reference (idx, count)
+        // recursive split over the root boxes; returns the child reference (idx, count)
+        uint32_t tlas_max_depth = 0;  // set per tree: depth of the balanced tree + 6
+        auto ceil_log2 = [](size_t n) { uint32_t d = 0; while (((size_t)1 << d) < n) ++d; return d; };
         std::function<void(std::vector<uint32_t>&, size_t, size_t, uint32_t, uint32_t&, uint32_t&, Box&)> build_tlas =
             [&](std::vector<uint32_t>& ms, size_t b0, size_t e0, uint32_t depth, uint32_t& idx, uint32_t& cnt, Box& box) {
                 if (depth > tlas_depth) tlas_depth = depth;
@@ -508,24 +510,53 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                     cnt = 1;
                     return;
                 }
-                float cmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-                for (size_t q = b0; q < e0; ++q) {
-                    const rt_node& r = nodes[meshes[ms[q]].node_offset];
-                    for (int k = 0; k < 3; ++k) {
-                        float c = 0.5f * r.aabb_min[k] + 0.5f * r.aabb_max[k];
-                        if (c < cmin[k]) cmin[k] = c;
-                        if (c > cmax[k]) cmax[k] = c;
+                // Split: surface-area heuristic over the root boxes, swept along each axis in centroid order (the
+                // boxes are few -- one per mesh -- so the full sweep is affordable; a median split put the scene-wide
+                // floor and ceiling meshes of the many-mesh stand-in into the same subtrees as the columns next to
+                // their centroids).  Any split is a correct one: the tree only has to contain its root boxes.
+                auto centroid_less = [&](int axis) {
+                    return [&, axis](uint32_t x, uint32_t y) {
+                        const rt_node &rx = nodes[meshes[x].node_offset], &ry = nodes[meshes[y].node_offset];
+                        const float cx = rx.aabb_min[axis] + rx.aabb_max[axis], cy = ry.aabb_min[axis] + ry.aabb_max[axis];
+                        return cx < cy || (cx == cy && x < y);
+                    };
+                };
+                auto half_area = [](const double* lo3, const double* hi3) {
+                    const double dx = hi3[0] - lo3[0], dy = hi3[1] - lo3[1], dz = hi3[2] - lo3[2];
+                    return dx * dy + dy * dz + dz * dx;
+                };
+                const size_t cnt_here = e0 - b0;
+                int best_axis = 0;
+                size_t best_left = cnt_here / 2;
+                double best_cost = DBL_MAX;
+                std::vector<double> right_area(cnt_here);
+                for (int axis = 0; axis < 3; ++axis) {
+                    std::sort(ms.begin() + b0, ms.begin() + e0, centroid_less(axis));
+                    double lo3[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi3[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+                    for (size_t q = cnt_here; q-- > 1;) {  // right_area[q]: boxes q .. end
+                        const rt_node& r = nodes[meshes[ms[b0 + q]].node_offset];
+                        for (int k = 0; k < 3; ++k) {
+                            if (r.aabb_min[k] < lo3[k]) lo3[k] = r.aabb_min[k];
+                            if (r.aabb_max[k] > hi3[k]) hi3[k] = r.aabb_max[k];
+                        }
+                        right_area[q] = half_area(lo3, hi3);
+                    }
+                    for (int k = 0; k < 3; ++k) { lo3[k] = DBL_MAX; hi3[k] = -DBL_MAX; }
+                    for (size_t q = 1; q < cnt_here; ++q) {  // left = boxes 0 .. q-1
+                        const rt_node& r = nodes[meshes[ms[b0 + q - 1]].node_offset];
+                        for (int k = 0; k < 3; ++k) {
+                            if (r.aabb_min[k] < lo3[k]) lo3[k] = r.aabb_min[k];
+                            if (r.aabb_max[k] > hi3[k]) hi3[k] = r.aabb_max[k];
+                        }
+                        const double cost = half_area(lo3, hi3) * (double)q + right_area[q] * (double)(cnt_here - q);
+                        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_left = q; }
                     }
                 }
-                int axis = 0;
-                if (cmax[1] - cmin[1] > cmax[axis] - cmin[axis]) axis = 1;
-                if (cmax[2] - cmin[2] > cmax[axis] - cmin[axis]) axis = 2;
-                std::sort(ms.begin() + b0, ms.begin() + e0, [&](uint32_t x, uint32_t y) {
-                    const rt_node &rx = nodes[meshes[x].node_offset], &ry = nodes[meshes[y].node_offset];
-                    float cx = rx.aabb_min[axis] + rx.aabb_max[axis], cy = ry.aabb_min[axis] + ry.aabb_max[axis];
-                    return cx < cy || (cx == cy && x < y);
-                });
-                const size_t mid = b0 + (e0 - b0) / 2;
+                // (every lane keeps a tree stack of depth + 2 entries in LDS: a subtree that would not fit below the
+                // depth limit any other way is split in the middle)
+                if (depth + ceil_log2(cnt_here) >= tlas_max_depth) best_left = cnt_here / 2;
+                std::sort(ms.begin() + b0, ms.begin() + e0, centroid_less(best_axis));
+                const size_t mid = b0 + best_left;
                 const uint32_t me = (uint32_t)tlas.size();
                 tlas.emplace_back();
                 uint32_t ai, ac, bi, bc;
@@ -610,6 +641,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 std::vector<uint32_t> ms = grouped;
                 uint32_t ridx, rcnt;
                 Box rb;
+                tlas_max_depth = 1 + ceil_log2(ms.size()) + 6;
                 build_tlas(ms, 0, ms.size(), 1, ridx, rcnt, rb);
                 items.push_back(Item{ITEM_TLAS | flag(), ridx, i0, (uint32_t)grouped.size()});
             }
