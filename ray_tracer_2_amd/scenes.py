@@ -63,8 +63,12 @@ def cornell_dragon(cornell_raw, dragon_raw, subdivide=3, device=None):
     return sc
 
 
-def _box_mesh(lo, hi):
-    """12 triangles, outward normals, per-face uv in [0, 1]; vertices8 + indices."""
+def _box_mesh(lo, hi, detail=1, rng=None):
+    """12 triangles, outward normals, per-face uv in [0, 1]; vertices8 + indices.  detail = k > 1: every face is a
+    k x k grid of quads (12 k^2 triangles) whose inner vertices are pushed in and out along the face normal (a
+    carved surface, so that the mesh's BVH is a real tree and not six coplanar sheets)."""
+    if detail > 1:
+        return _carved_box_mesh(lo, hi, detail, rng)
     lo, hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
     faces = [  # (origin, du, dv, normal)
         ((lo[0], lo[1], hi[2]), (hi[0] - lo[0], 0, 0), (0, hi[1] - lo[1], 0), (0, 0, 1)),
@@ -85,12 +89,44 @@ def _box_mesh(lo, hi):
     return np.array(v, np.float32), np.array(idx, np.uint32)
 
 
-def sponza_standin(n_meshes=200, seed=11):
+def _carved_box_mesh(lo, hi, k, rng):
+    lo, hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+    ext = hi - lo
+    faces = [((lo[0], lo[1], hi[2]), (ext[0], 0, 0), (0, ext[1], 0), (0, 0, 1)),
+             ((hi[0], lo[1], lo[2]), (-ext[0], 0, 0), (0, ext[1], 0), (0, 0, -1)),
+             ((hi[0], lo[1], hi[2]), (0, 0, -ext[2]), (0, ext[1], 0), (1, 0, 0)),
+             ((lo[0], lo[1], lo[2]), (0, 0, ext[2]), (0, ext[1], 0), (-1, 0, 0)),
+             ((lo[0], hi[1], hi[2]), (ext[0], 0, 0), (0, 0, -ext[2]), (0, 1, 0)),
+             ((lo[0], lo[1], lo[2]), (ext[0], 0, 0), (0, 0, ext[2]), (0, -1, 0))]
+    g = np.arange(k + 1, dtype=np.float32) / np.float32(k)
+    aa, bb = np.meshgrid(g, g, indexing="xy")
+    inner = ((aa > 0) & (aa < 1) & (bb > 0) & (bb < 1)).astype(np.float32)
+    depth = np.float32(0.04 * float(min(ext[ext > 0].min(), 20.0)))
+    vs, ids = [], []
+    q = (np.arange(k)[:, None] * (k + 1) + np.arange(k)[None, :]).reshape(-1).astype(np.uint32)
+    quad = np.stack([q, q + 1, q + k + 2, q, q + k + 2, q + k + 1], 1).reshape(-1)
+    for o, du, dv, n in faces:
+        o, du, dv, n = (np.asarray(x, np.float32) for x in (o, du, dv, n))
+        bump = (rng.uniform(-1.0, 1.0, aa.shape).astype(np.float32) * inner * depth)[..., None]
+        pos = o + aa[..., None] * du + bb[..., None] * dv + bump * n
+        v = np.zeros(((k + 1) * (k + 1), 8), np.float32)
+        v[:, 0:3] = pos.reshape(-1, 3)
+        v[:, 3:6] = n
+        v[:, 6] = 2.0 * aa.reshape(-1)
+        v[:, 7] = 2.0 * bb.reshape(-1)
+        ids.append(quad + np.uint32(sum(len(x) for x in vs)))
+        vs.append(v)
+    return np.concatenate(vs), np.concatenate(ids).astype(np.uint32)
+
+
+def sponza_standin(n_meshes=200, seed=11, detail=1):
     """BASELINE config 4 stand-in (sponza.obj and 4 of its textures are missing from the checkout):
     a many-mesh textured atrium with the structure of Scene::sponza (scene.rs:864-910) -- one OBJ's
     worth of groups sharing a single transform of scale 0.05, textured materials, plus the emissive
     quad and the emissive sphere -- built procedurally: a floor, a ceiling band, and rows of columns
-    and blocks (12 triangles each), `n_meshes` meshes in all, 8 procedural textures."""
+    and blocks (12 triangles each), `n_meshes` meshes in all, 8 procedural textures.  `detail` = k > 1 carves every
+    face into a k x k grid (12 k^2 triangles per mesh): `sponza_standin(340, detail=8)` has sponza.obj's size
+    (261 k triangles in some hundreds of groups) and no longer fits the LDS."""
     rng = np.random.RandomState(seed)
     sc = Scene()
     sc.set_camera((0, 4, 0), (0, 4, 1))   # scene.rs:867-870
@@ -118,7 +154,7 @@ def sponza_standin(n_meshes=200, seed=11):
         boxes.append(((x - w, 0, zc - d), (x + w, hgt, zc + d)))
         k += 1
     for i, (lo, hi) in enumerate(boxes[:n_meshes]):
-        v, idx = _box_mesh(lo, hi)
+        v, idx = _box_mesh(lo, hi, detail, rng)
         sc.add_mesh_from_data(v, idx, xform=xf, mat=textured(i))
     h = float(np.sin(np.pi / 4)), float(np.cos(np.pi / 4))
     quad = np.array([[-1, -1, 0, 0, 0, 1, 0, 0], [1, -1, 0, 0, 0, 1, 1, 0], [1, 1, 0, 0, 0, 1, 1, 1], [-1, 1, 0, 0, 0, 1, 0, 1]], np.float32)

@@ -240,10 +240,11 @@ def dragon_arrays(rt):
     return rt.SceneArrays.from_scene(sc)
 
 
-def _random_scene(rt, seed):
+def _random_scene(rt, seed, many=False):
     """A seeded random scene: boxes/blobs of random triangles in several transform groups (so forest
     items, singles and root-leaf meshes all occur), random materials (diffuse, glossy, glass, emissive,
-    textured), spheres, sometimes depth of field."""
+    textured), spheres, sometimes depth of field.  many: 5 to 40 meshes per transform group (top-level
+    trees over the groups' root boxes, of random shape)."""
     rng = np.random.default_rng(seed)
     sc = rt.Scene()
     dof = seed % 3 == 0
@@ -287,8 +288,9 @@ def _random_scene(rt, seed):
         q = q / np.linalg.norm(q)
         xf = None if g == 0 else rt.transform(pos=tuple(rng.uniform(-1, 1, 3) + (0, 0.8, 0)), rot=tuple(q),
                                               scale=tuple(rng.uniform(0.5, 1.5, 3)))
-        for m in range(int(rng.integers(1, 5))):  # meshes sharing it
-            v, i = blob(int(rng.integers(1, 40)), rng.uniform(-1.2, 1.2, 3) * (1, 0.4, 1) + (0, 0.7, 0), float(rng.uniform(0.2, 0.6)))
+        for m in range(int(rng.integers(5, 41)) if many else int(rng.integers(1, 5))):  # meshes sharing it
+            v, i = blob(int(rng.integers(1, 40)), rng.uniform(-1.2, 1.2, 3) * (1, 0.4, 1) + (0, 0.7, 0),
+                        float(rng.uniform(0.05, 0.3) if many else rng.uniform(0.2, 0.6)))
             sc.add_mesh_from_data(v, i, xform=xf, mat=mat())
     for k in range(int(rng.integers(0, 3))):
         sc.add_sphere(tuple(rng.uniform(-1.5, 1.5, 3) * (1, 0.3, 1) + (0, 0.6, 0)), float(rng.uniform(0.2, 0.6)), mat())
@@ -318,6 +320,34 @@ def test_random_scenes(rt, oracle, tracer, seed):
             assert same(tracer.read_image(96, 54), ref), (seed, variant, "product kernel")
     finally:
         tracer.set_option("kernel_variant", -1)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_many_mesh_scenes(rt, oracle, tracer, seed):
+    """Seeded random scenes with 5-40 meshes per transform group: top-level trees of random shape (and, with
+    tlas_min = 2, over every pair of eligible meshes), both kernel variants, image and traversal counters."""
+    arrays = _random_scene(rt, 1000 + seed, many=True)
+    p = rt.make_params(80, 45, 4, 2, skybox=seed % 2, frames=0)
+    ref, st = oracle.render(p, arrays)
+    try:
+        for tlas_min in (8, 2):
+            tracer.set_option("tlas_min", tlas_min)
+            tracer.load_scene(arrays)
+            for variant in (0, 1):
+                tracer.set_option("kernel_variant", variant)
+                tracer.set_counters(True)
+                tracer.reset_timing()
+                tracer.render(p)
+                gpu = tracer.read_image(80, 45)
+                s = tracer.stats()
+                tracer.set_counters(False)
+                assert same(gpu, ref), (seed, tlas_min, variant)
+                assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests), (seed, tlas_min, variant)
+                tracer.render(p)
+                assert same(tracer.read_image(80, 45), ref), (seed, tlas_min, variant, "product kernel")
+    finally:
+        tracer.set_option("kernel_variant", -1)
+        tracer.set_option("tlas_min", 8)
 
 
 @pytest.mark.parametrize("knobs", [{"forest": 0}, {"stack_wide": 1}, {"stack_wide": 0}, {"pixel_cache": 0}, {"pixel_cache": 2}, {"primary_table": 0},
@@ -500,6 +530,35 @@ def test_config4_sponza_standin(rt, oracle, tracer):
         pd = rt.make_params(192, 108, 4, 1, debug_flag=dbg, debug_scale=500)
         gpu, ref, _, _ = render_both(rt, oracle, tracer, a, pd)
         assert same(gpu, ref), dbg
+
+
+def test_config4_sponza_sized_standin(rt, oracle, tracer):
+    """The config 4 stand-in at sponza.obj's size (340 meshes of 768 triangles: 261 k triangles, the scene is
+    read from global memory under the top-level tree) -- image and counters bit for bit, both kernel variants,
+    with and without the tree, and three accumulated frames in one launch."""
+    from ray_tracer_2_amd import scenes
+    a = rt.SceneArrays.from_scene(scenes.sponza_standin(340, detail=8))
+    assert a.meshes.shape[0] == 341 and a.triangles.shape[0] == 340 * 768 + 2
+    p = rt.make_params(160, 90, 4, 2, skybox=1, frames=0)
+    for variant, tlas in ((0, 1), (1, 1), (0, 0)):
+        tracer.set_option("kernel_variant", variant)
+        tracer.set_option("tlas", tlas)
+        tracer.set_counters(True)
+        gpu, ref, s, st = render_both(rt, oracle, tracer, a, p)
+        tracer.set_counters(False)
+        assert same(gpu, ref), (variant, tlas)
+        assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests)
+    tracer.set_option("kernel_variant", -1)
+    tracer.set_option("tlas", 1)
+    acc = np.zeros((90, 160, 4), np.float32)
+    for f in range(3):
+        p.frames = f
+        acc, _ = oracle.render(p, a, image=acc)
+    p.frames = 0
+    tracer.load_scene(a)
+    tracer.write_image(np.zeros((90, 160, 4), np.float32))
+    tracer.render_frames(p, 3)
+    assert same(tracer.read_image(160, 90), acc)
 
 
 @pytest.mark.parametrize("case", ["cornell", "dragon_x9", "soup"])

@@ -23,7 +23,7 @@ def main():
     if n < 0:
         arrays = rt.SceneArrays.load(os.path.join(g, "cornell_scene.npz"))
     elif n == 0:
-        arrays = rt.SceneArrays.from_scene(scenes.sponza_standin(200))
+        arrays = rt.SceneArrays.from_scene(scenes.sponza_standin(int(os.environ.get("BS_MESHES", 200)), detail=int(os.environ.get("BS_DETAIL", 1))))
     else:
         arrays = rt.SceneArrays.from_scene(scenes.cornell_dragon(scenes.load_raw_meshes(os.path.join(g, "cornell_raw.npz")),
                                                                  scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")), subdivide=n, device=0))

@@ -4,7 +4,8 @@ bytes SURVEY 8(d) item (ii) asks for:
     python tools/bench_scene.py 3 16          # config 3 stand-in: dragon x9 in the Cornell box, 1920x1080, 16 spp, 4 bounces
     BS_W=3840 BS_H=2160 BS_BOUNCES=8 python tools/bench_scene.py 11 64    # config 5 stand-in at full size
     python tools/bench_scene.py 0 8           # config 4 stand-in: 200 textured meshes
-Options: BS_OPTS=name=value,... (rt_set_option, upload-time ones too), BS_FRAMES (timed frames, default 12),
+    BS_MESHES=340 BS_DETAIL=8 python tools/bench_scene.py 0 8    # the same at sponza.obj's size (261 k triangles)
+Options: BS_OPTS=name=value,... (rt_set_option, upload-time ones too), BS_FRAMES (timed frames, default: whole launches, >= 12),
 BS_BATCH (frames per launch of rt_render_frames, default 4; 1 = one launch per frame), BS_JSON=path (also write the
 figures as JSON), BS_COUNTERS=0 (skip the counter frame), BS_DEVICE_BUILD=1 (SAH searches on the GPU).
 Demand bytes per segment = node tests x 48 + triangle tests x 96 + meshes x 240 (the reference's records: Node 48 B,
@@ -27,8 +28,9 @@ def main():
     g = os.path.join(ROOT, "tests", "golden")
     t0 = time.perf_counter()
     if n == 0:   # config 4 stand-in: many textured meshes
-        sc = scenes.sponza_standin(200)
-        name = "sponza stand-in (200 textured meshes)"
+        nm, detail = int(os.environ.get("BS_MESHES", 200)), int(os.environ.get("BS_DETAIL", 1))
+        sc = scenes.sponza_standin(nm, detail=detail)
+        name = f"sponza stand-in ({nm} textured meshes, {12 * detail * detail} triangles each)"
     else:
         sc = scenes.cornell_dragon(scenes.load_raw_meshes(os.path.join(g, "cornell_raw.npz")),
                                    scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")), subdivide=n,
@@ -38,19 +40,20 @@ def main():
     arrays = rt.SceneArrays.from_scene(sc)
     W, H = (int(os.environ.get("BS_W", 1920)), int(os.environ.get("BS_H", 1080)))
     NB = int(os.environ.get("BS_BOUNCES", 4))
-    frames = int(os.environ.get("BS_FRAMES", 12))
-    batch = int(os.environ.get("BS_BATCH", 4))
+    batch = max(1, int(os.environ.get("BS_BATCH", 4)))
+    frames = int(os.environ.get("BS_FRAMES", 0)) or batch * max(2, 12 // batch)   # whole launches of `batch` frames
+    per_launch = -(-frames // -(-frames // batch))   # rt_render_frames cuts n frames into equal batches
     tr = rt.RayTracer(0, W, H)
     for kv in os.environ.get("BS_OPTS", "").split(","):   # e.g. BS_OPTS=forest=0,tlas=0 (upload-time options too)
         if kv:
             k, v = kv.split("=")
             tr.set_option(k, int(v))
-    tr.set_option("batch_frames", max(1, batch))
+    tr.set_option("batch_frames", batch)
     tr.load_scene(arrays)
     n_tri, n_nodes, n_mesh = arrays.triangles.shape[0], arrays.nodes.shape[0], arrays.meshes.shape[0]
     print(f"{name}: triangles {n_tri}, nodes {n_nodes}, meshes {n_mesh}; host build {build_s:.2f} s", flush=True)
     out = {"scene": name, "triangles": n_tri, "nodes": n_nodes, "meshes": n_mesh, "width": W, "height": H, "spp": spp,
-           "bounces": NB, "frames_per_launch": batch}
+           "bounces": NB, "frames_per_launch": per_launch}
     # warm-up (also gives the tile order), then timed frames
     tr.render_frames(rt.make_params(W, H, NB, spp, skybox=1, frames=0), max(2, batch))
     ts = []
@@ -66,7 +69,7 @@ def main():
     rays = st.segments / st.frames
     out.update(ms_per_frame=ms, kernel_ms_per_frame=st.kernel_ms / st.frames, rays_per_frame=rays,
                rays_traversed_per_frame=(st.segments - st.segments_reused) / st.frames, mrays_per_s=rays / ms / 1e3)
-    print(f"{ms:.3f} ms/frame ({st.kernel_ms / st.frames:.3f} in kernels, {batch} frames per launch), {rays / ms / 1e3:.0f} Mrays/s, "
+    print(f"{ms:.3f} ms/frame ({st.kernel_ms / st.frames:.3f} in kernels, {per_launch} frames per launch), {rays / ms / 1e3:.0f} Mrays/s, "
           f"{rays / 1e6:.2f} Mrays/frame ({(st.segments - st.segments_reused) / st.frames / 1e6:.2f} M traversed)", flush=True)
     if os.environ.get("BS_COUNTERS", "1") != "0":
         # one frame with the shader's stats counters (wgsl:307,322) compiled in

@@ -57,7 +57,7 @@ def main():
                                                                  scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")), 3))
     elif os.environ.get("DIAG_SCENE") == "sponza":
         from ray_tracer_2_amd import scenes
-        arrays = rt.SceneArrays.from_scene(scenes.sponza_standin(200))
+        arrays = rt.SceneArrays.from_scene(scenes.sponza_standin(int(os.environ.get("BS_MESHES", 200)), detail=int(os.environ.get("BS_DETAIL", 1))))
     else:
         arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
     tr = rt.RayTracer(0, W, H)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stress version of tests/test_gpu_scenes.py::test_random_scenes: N seeded random scenes, GPU (both kernel
 variants, with and without counters, one launch per frame; and three accumulating frames as one batch of
-rt_render_frames) against the CPU oracle, bit for bit.  usage: fuzz_parity.py [first] [count]"""
+rt_render_frames) against the CPU oracle, bit for bit.  Every fourth scene is a many-mesh one (top-level trees).  usage: fuzz_parity.py [first] [count]"""
 import os
 import sys
 
@@ -18,7 +18,8 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 tr = rt.RayTracer(0, 256, 256)
 bad = 0
 for seed in range(first, first + count):
-    arrays = _random_scene(rt, seed)
+    arrays = _random_scene(rt, seed, many=seed % 4 == 3)   # every fourth: 5-40 meshes per transform group (top-level trees)
+    tr.set_option("tlas_min", 2 if seed % 8 == 7 else 8)
     w, h = 64 + 8 * (seed % 9), 40 + 4 * (seed % 7)
     p = rt.make_params(w, h, 1 + seed % 6, 1 + seed % 4, skybox=seed % 2, frames=0)
     ref, st = oracle.render(p, arrays)
