@@ -495,6 +495,8 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             }
             return true;
         };
+        // (a tree's reference to a mesh has 9 bits for the mesh and 21 for its root record, rt_device.h)
+        auto tree_ok = [&](uint32_t i) { return root_box_ok(i) && i <= TLAS_REF_MESH_MASK && root_idx[i] <= TLAS_REF_ROOT_MASK; };
         struct Box { float lo[3], hi[3]; };
         auto asf2 = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
         // recursive split over the root boxes; returns the child reference (idx, count)
@@ -506,7 +508,8 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 if (e0 - b0 == 1) {
                     const rt_node& r = nodes[meshes[ms[b0]].node_offset];
                     for (int k = 0; k < 3; ++k) { box.lo[k] = r.aabb_min[k]; box.hi[k] = r.aabb_max[k]; }
-                    idx = ms[b0];
+                    idx = root_idx[ms[b0]] | (ms[b0] << TLAS_REF_MESH_SHIFT) |
+                          (meshes[ms[b0]].material.flag == RT_MATERIAL_GLASS ? TLAS_REF_GLASS : 0u);
                     cnt = 1;
                     return;
                 }
@@ -583,7 +586,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             for (uint32_t i0 = 0; i0 < n_meshes;) {
                 uint32_t i1 = i0 + 1, ok = 0;
                 while (i1 < n_meshes && memcmp(meshes[i1].world_to_model, meshes[i0].world_to_model, 64) == 0) ++i1;
-                for (uint32_t i = i0; i < i1; ++i) ok += root_box_ok(i) ? 1u : 0u;
+                for (uint32_t i = i0; i < i1; ++i) ok += tree_ok(i) ? 1u : 0u;
                 if (ok >= (uint32_t)h->tlas_min) any_tlas = true;
                 i0 = i1;
             }
@@ -600,7 +603,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             std::vector<uint32_t> grouped;
             if (h->use_tlas)
                 for (uint32_t i = i0; i < i1; ++i)
-                    if (root_box_ok(i)) grouped.push_back(i);
+                    if (tree_ok(i)) grouped.push_back(i);
             if (grouped.size() < (size_t)h->tlas_min) grouped.clear();
             // the other meshes of the run with an internal, non-deep root (and the run's
             // model_to_world as well) form a forest when there are at least two of them

@@ -50,6 +50,16 @@ constexpr uint32_t ITEM_BYTES = 32;
 //        near leaf first: the few-mesh kernels run it as straight-line code with every lane of the wave in step,
 //        no stack and no loop (traverse_flat2), instead of as a forest member or a mesh walk.
 enum : uint32_t { ITEM_TLAS = 1u, ITEM_NEW_XFORM = 2u, ITEM_FOREST = 4u, ITEM_FLAT2 = 8u };
+// A top-level tree's reference to a mesh (the child index of a tree record whose child count is non-zero; with bit
+// 31 set, an entry of the tree stack): everything a lane needs to enter the mesh -- the mesh's index (the caps allow
+// 400), the absolute index of its root's wide record (<= 1.3 M internal nodes) and whether it is glass (wgsl:376: no
+// backface culling).  Meshes that do not fit these fields stay single items.
+enum : uint32_t {
+    TLAS_REF_ROOT_MASK = 0x001fffffu,  // bits 0-20
+    TLAS_REF_MESH_SHIFT = 21u,
+    TLAS_REF_MESH_MASK = 0x1ffu,       // bits 21-29
+    TLAS_REF_GLASS = 0x40000000u,      // bit 30
+};
 // Forest member entry, 3 x 16 B: q0 = (root wide index, mesh index, flags, 0), q1/q2 = the root's
 // packed box (as in a wide record).  flags: DMESH_GLASS, FOREST_CULLABLE = the root box provably
 // contains the boxes of the root's children (so missing it means missing the mesh).

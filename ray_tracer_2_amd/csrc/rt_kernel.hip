@@ -823,13 +823,20 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                 visit_mesh(ia, hdr);
             }
         } else {
-            // Many-mesh kernels: one traversal loop serves single meshes (a one-entry stack)
-            // and top-level trees, so the mesh visit is instantiated once.
-            uint32_t tsp = 0;
+            // Many-mesh kernels: one traversal loop serves single meshes and top-level trees, so the mesh walk is
+            // instantiated once.  The walk's state (see below):
+            const LaneStack st{stack, a.stack_wide != 0u};
+            const uint32_t tri0 = a.lay.tri_off;
+            uint32_t cur = 0, cur_count = 0, sp = 0, mesh = 0, tsp = 0;
+            bool have = false, cull = false;
+            MeshBest b;
+            b.t = INF;
+            b.tri = 0xffffffffu;
+            b.u = b.v = 0.0f;
             if ((kind & ITEM_TLAS) == 0u) {
                 bool may_hit = true;
-                const uint32_t root_count = fbits(ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16).z);
-                if (a.cull_roots && root_count == 0u) {
+                const float4 hdr = ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16);  // (flags, root, root count)
+                if (a.cull_roots && fbits(hdr.z) == 0u) {
                     // Mesh-level culling that cannot change the result.  The shader
                     // never tests the root box, only its two children (wgsl:316-321) -- but the
                     // root box contains the child boxes and IEEE subtraction / multiplication /
@@ -840,13 +847,20 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                     const uint32_t mo = a.lay.mesh_off + ia * MESH_REC_BYTES;
                     const float4 rmin = ld4<LDS>(a, mo + 160), rmax = ld4<LDS>(a, mo + 176);
                     may_hit = !cull_ok || aabb_dist(lo, inv, rmin, rmax, INF) < INF;
+                    // (a culled mesh -- always one with an internal root -- still counts its two root-level tests)
+                    if (STATS && !may_hit) node_tests += 2;
                 }
-                // counter bookkeeping: the leaf branch below subtracts the two root-level tests that
-                // traverse_mesh counts again; a culled mesh (always an internal root) keeps them
-                if (STATS) node_tests += 2;
                 if (may_hit) {
-                    tstack[0] = ia | 0x80000000u;
-                    tsp = 1;
+                    const uint32_t flags = fbits(hdr.x);
+                    if ((flags & DMESH_DEEP) != 0u) {
+                        visit_mesh(ia, hdr);  // (the shader's literal stack: walked on its own)
+                    } else {
+                        mesh = ia;
+                        cur = fbits(hdr.y);
+                        cur_count = fbits(hdr.z);
+                        cull = (flags & DMESH_GLASS) == 0u;
+                        have = true;
+                    }
                 }
             } else {
                 // Top-level tree over the root boxes of fbits(item.w) meshes (all with internal
@@ -862,20 +876,15 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             // common node-visit and triangle passes and fetch the next candidate as they finish (like a forest
             // item) -- instead of every lane walking a whole mesh to the end, the wave in step, each time one of its
             // tree pops is a mesh.  Per lane the meshes are visited in the same order and every mesh's walk is
-            // traverse_mesh's, entry for entry; the counters are kept as before.
+            // traverse_mesh's, entry for entry; the counters are kept as before.  A tree's reference to a mesh
+            // (TLAS_REF_*, rt_device.h) carries the mesh's index, its root record and its culling rule, so entering
+            // a mesh costs no load (it was a dependent one, of the mesh header: 13 % of the loads on a ray's
+            // critical path in the sponza-sized scene).
             // (Measured on the 200-mesh stand-in: 9.0 -> 7.9 ms per frame.  Going one step further -- tree nodes and
             // mesh nodes visited in the SAME passes, one walk over both levels -- was 9.0 again: the passes did not
             // merge, 45 per iteration instead of 35 + 14, because a wave-iteration lasts as long as its longest ray
             // and that ray's tree and mesh visits are sequential either way.)
             {
-                const LaneStack st{stack, a.stack_wide != 0u};
-                const uint32_t tri0 = a.lay.tri_off;
-                uint32_t cur = 0, cur_count = 0, sp = 0, mesh = 0;
-                bool have = false, cull = false;
-                MeshBest b;
-                b.t = INF;
-                b.tri = 0xffffffffu;
-                b.u = b.v = 0.0f;
                 for (;;) {
                     TIC(t8);
                     if (!have) {
@@ -888,18 +897,11 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                             const uint32_t e = tstack[tsp * 64];
                             if (e & 0x80000000u) {
                                 DIAG(18);
-                                const uint32_t mi = e & 0x7fffffffu;
-                                const float4 hdr = ld4<LDS>(a, a.lay.mesh_off + mi * MESH_REC_BYTES + 128);
                                 if (STATS) node_tests -= 2;  // counted above; the walk counts them again
-                                const uint32_t flags = fbits(hdr.x);
-                                if ((flags & DMESH_DEEP) != 0u) {
-                                    visit_mesh(mi, hdr);  // (the shader's literal stack: walked on its own)
-                                    continue;
-                                }
-                                mesh = mi;
-                                cur = fbits(hdr.y);
-                                cur_count = fbits(hdr.z);
-                                cull = (flags & DMESH_GLASS) == 0u;
+                                mesh = (e >> TLAS_REF_MESH_SHIFT) & TLAS_REF_MESH_MASK;
+                                cur = e & TLAS_REF_ROOT_MASK;
+                                cur_count = 0;
+                                cull = (e & TLAS_REF_GLASS) == 0u;
                                 b.t = INF;
                                 sp = 0;
                                 have = true;
