@@ -717,10 +717,12 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
     bool cull_ok = false;
     auto accept_hit = [&](uint32_t i, const CompactHit& b) {
         DIAG(10);
+        TIC(t19);
         f3 whp;
         float wdst;
         world_hit<LDS>(a, a.lay.mesh_off + i * MESH_REC_BYTES + 64u, lo, ld, ro, b.t, whp, wdst);
         isect_offer(I, i, b, whp, wdst);
+        TOC(t19, 19);
     };
     auto accept_mesh_hit = [&](uint32_t i, const MeshBest& b) { accept_hit(i, compact(b)); };
     // Deferred offers.  The meshes every lane visits together (root-leaf and two-leaf items) are hit by a few lanes
@@ -816,8 +818,10 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                 b.t = INF;
                 b.tri = 0xffffffffu;
                 b.u = b.v = 0.0f;
+                TIC(t18);
                 traverse_flat2<LDS, STATS>(a, __builtin_amdgcn_readfirstlane(fbits(hdr.y)), (fbits(hdr.x) & DMESH_GLASS) == 0, lo, ld, inv,
                                            b, node_tests, tri_tests);
+                TOC(t18, 18);
                 if (b.tri != 0xffffffffu) offer_later(ia, b);
             } else {
                 visit_mesh(ia, hdr);

@@ -25,7 +25,7 @@ TIMED = {0: "intersect_scene (all)", 1: "sample start (ray gen / memo ray)", 2: 
          4: "root-leaf meshes", 5: "forest: root-box marks", 6: "forest: node visits", 7: "forest: leaf triangles",
          8: "forest: deal tasks, fetch rays", 9: "winner finalize", 10: "miss: sky", 11: "memo hit load",
          12: "shade (hit)", 13: "memo hit store", 14: "refill / tile pull", 15: "path_step (all)",
-         16: "single-mesh BVH walk", 17: "forest: world hit + results back"}
+         16: "single-mesh BVH walk", 17: "forest: world hit + results back", 18: "two-leaf meshes", 19: "mesh hit -> world, offer"}
 
 
 def build_timed():
