@@ -29,6 +29,7 @@ hipError_t launch_tile_order(const uint32_t* cost, uint32_t n_tiles, uint32_t ma
                              hipStream_t stream);
 hipError_t launch_primary(const RenderArgs& a, float* table, hipStream_t stream);
 hipError_t launch_blend_frames(const BlendArgs& b, hipStream_t stream);
+hipError_t launch_walk(const RenderArgs& a, uint32_t compute_units, hipStream_t stream);
 hipError_t launch_units(int fn, const float* x, const float* y, float* out, unsigned long long n, hipStream_t stream);
 hipError_t launch_units_texture(const uint8_t* rgba8, uint32_t width, uint32_t height, const float* srgb_lut, const float* uv,
                                 float* out, unsigned long long n, hipStream_t stream);
@@ -57,6 +58,13 @@ struct rt_handle {
     // frame batches (rt_render_frames): scratch images of the frames in flight
     float4* batch_scratch = nullptr;
     size_t batch_scratch_texels = 0;
+    // deferred walks (RenderArgs::park): the deferred mesh found at upload, the two park queues, their counters
+    bool have_defer = false;
+    uint32_t defer_mesh = 0, defer_xform = 0;
+    int sort_rounds = 0;  // option "sort_rounds": render launches that park, after which one launch runs what is left (0 = off)
+    float4* park_queue[2] = {nullptr, nullptr};
+    size_t park_capacity = 0;  // records per queue
+    uint32_t* park_counts = nullptr;
     int batch_tile_major = 1;  // option "batch_tile_major": (tile, frame) instead of (frame, tile) order of a batch's work items
     int batch_frames_opt = 16;  // option "batch_frames": frames per launch of rt_render_frames (1..RT_MAX_BATCH_FRAMES)
     // rt_render_multi: what the root's stream has to finish before this handle's image may be overwritten
@@ -348,6 +356,9 @@ void rt_destroy(rt_handle* h) {
     free_dev(h->multi_gathered);
     free_dev(h->multi_frame);
     free_dev(h->batch_scratch);
+    free_dev(h->park_queue[0]);
+    free_dev(h->park_queue[1]);
+    free_dev(h->park_counts);
     if (h->multi_event) (void)hipEventDestroy(h->multi_event);
     for (hipEvent_t e : h->multi_copied_events) (void)hipEventDestroy(e);
     if (g_rccl.lib)
@@ -655,6 +666,36 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         const uint32_t tlas_entries = tlas.empty() ? 1u : tlas_depth + 2u;
         const bool has_tlas = !tlas.empty();
 
+        // ---- the deferred mesh (RenderArgs::park) ----------------------------------------------
+        // The biggest single-mesh item of a few-mesh scene with a real BVH (not the shader's literal-stack kind):
+        // its item goes to the end of the mesh loop (the loop's order is free), where a launch can stop in front
+        // of it.
+        bool have_defer = false;
+        uint32_t defer_mesh = 0, defer_xform = 0;
+        if (!any_tlas && n_meshes < 16) {
+            size_t best_k = items.size();
+            uint32_t best_big = 0;
+            for (size_t k = 0; k < items.size(); ++k) {
+                const Item& it = items[k];
+                if (it.kind & (ITEM_TLAS | ITEM_FOREST | ITEM_FLAT2)) continue;
+                const uint32_t mi = it.a;
+                if (root_count[mi] != 0 || deep[mi]) continue;
+                const uint32_t internal = (mi + 1 < n_meshes ? wide_base[mi + 1] : (uint32_t)wide.size()) - wide_base[mi];
+                if (internal >= 1024 && internal > best_big) { best_big = internal; best_k = k; }
+            }
+            if (best_k < items.size()) {
+                Item d = items[best_k];
+                items.erase(items.begin() + (std::ptrdiff_t)best_k);
+                // (the item that followed it in the same local space now opens that space)
+                if ((d.kind & ITEM_NEW_XFORM) && best_k < items.size() && !(items[best_k].kind & ITEM_NEW_XFORM)) items[best_k].kind |= ITEM_NEW_XFORM;
+                d.kind |= ITEM_NEW_XFORM | ITEM_DEFER | (root_box_ok(d.a) ? ITEM_DEFER_CULL : 0u);
+                items.push_back(d);
+                have_defer = true;
+                defer_mesh = d.a;
+                defer_xform = d.b;
+            }
+        }
+
         // ---- blob layout ------------------------------------------------------
         SceneLayout lay{};
         uint64_t off = 0;
@@ -767,6 +808,9 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->n_items = (uint32_t)items.size();
         h->top_base = top_mesh_base;
         h->top_available = top_mesh_records >= 64 ? std::min<uint32_t>(top_mesh_records, 2048u) : 0u;
+        h->have_defer = have_defer;
+        h->defer_mesh = defer_mesh;
+        h->defer_xform = defer_xform;
         // LDS residency: blob + the four waves' stacks, cost tables and lane state within the
         // per-workgroup budget (the primary-ray memo goes to LDS only if it still fits, see render_impl)
         uint64_t stacks = ((uint64_t)h->stack_entries * (h->stack_wide ? 128u : 64u) + (uint64_t)h->tlas_entries * 64u) * sizeof(uint32_t) * WAVES_PER_BLOCK +
@@ -856,6 +900,9 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         h->cull_roots = value;
     } else if (n == "lds_scene") {
         h->force_global = value ? 0 : 1;
+    } else if (n == "sort_rounds") {
+        if (value < 0 || value > 64) return fail(h, RT_ERR_INVALID_ARGUMENT, "sort_rounds must be 0 (off) .. 64");
+        h->sort_rounds = value;
     } else if (n == "lds_top") {
         if (value < -1 || value > 2048) return fail(h, RT_ERR_INVALID_ARGUMENT, "lds_top must be -1 (auto), 0 (off) or a record count <= 2048");
         h->lds_top = value;
@@ -1045,6 +1092,9 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     const uint32_t n_tiles = a.tiles_x * a.tiles_y;
     a.tile_order = nullptr;
     a.tile_cost = nullptr;
+    // deferred walks (RenderArgs::park): path-trace frames of a few-mesh scene with one big mesh, persistent kernel
+    const bool rounds = h->sort_rounds > 0 && h->have_defer && a.many_mesh == 0 && a.kernel_variant == 0 && params->debug_flag == 0 &&
+                        params->rays_per_pixel > 0;
     if (h->tile_feedback && params->debug_flag == 0 && n_tiles <= h->tile_capacity && n_tiles > 0 && a.kernel_variant == 0) {
         const bool same_shape = h->history_valid && h->hist_w == params->width && h->hist_h == params->height &&
                                 h->hist_rank == rank && h->hist_world == world;
@@ -1095,7 +1145,61 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     }
     auto& ev = h->ev_pool[h->ev_used++];
     HIP_TRY(h, hipEventRecord(ev.first, h->stream));
-    HIP_TRY(h, launch_render(a, h->stream));
+    if (!rounds) {
+        HIP_TRY(h, launch_render(a, h->stream));
+    } else {
+        // launch 0 takes the tiles and parks every pixel in front of its first entry into the big mesh; then, round
+        // after round, rt_walk_kernel walks the mesh for the parked rays and a render launch resumes those pixels
+        // (parking them again at their next entry); the last render launch does not park: it walks what is left
+        // inline.  Everything is ordered on the stream; a launch whose queue is empty ends at once.
+        const size_t cap = (size_t)need_texels * (n_batch ? n_batch : 1u);
+        if (h->park_capacity < cap) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            free_dev(h->park_queue[0]);
+            free_dev(h->park_queue[1]);
+            h->park_capacity = 0;
+            const size_t bytes = ((cap + 63) / 64) * (size_t)PARK_PLANES * 64u * sizeof(float4);
+            HIP_TRY(h, hipMalloc((void**)&h->park_queue[0], bytes));
+            HIP_TRY(h, hipMalloc((void**)&h->park_queue[1], bytes));
+            h->park_capacity = cap;
+        }
+        if (!h->park_counts) HIP_TRY(h, hipMalloc((void**)&h->park_counts, 72 * sizeof(uint32_t)));
+        HIP_TRY(h, hipMemsetAsync(h->park_counts, 0, 72 * sizeof(uint32_t), h->stream));
+        a.defer_mesh = h->defer_mesh;
+        a.defer_xform = h->defer_xform;
+        auto fresh_counter = [&]() -> hipError_t {
+            h->work_slot = (h->work_slot + 1) & 63u;
+            if (h->work_slot == 0u) {
+                hipError_t e = hipMemsetAsync(h->work_counters, 0, 64 * sizeof(uint32_t), h->stream);
+                if (e != hipSuccess) return e;
+            }
+            a.work_counter = h->work_counters + h->work_slot;
+            return hipSuccess;
+        };
+        const uint32_t R = (uint32_t)h->sort_rounds;
+        a.park = 1;
+        a.q_in = nullptr;
+        a.q_in_count = nullptr;
+        a.q_out = h->park_queue[0];
+        a.q_out_count = h->park_counts;
+        HIP_TRY(h, launch_render(a, h->stream));
+        for (uint32_t r = 0; r < R; ++r) {
+            const bool last = r + 1 == R;
+            a.q_in = h->park_queue[r & 1u];
+            a.q_in_count = h->park_counts + r;
+            HIP_TRY(h, fresh_counter());
+            {
+                RenderArgs w = a;
+                w.top_count = 0;  // (nothing is staged into the walk kernel's LDS)
+                HIP_TRY(h, launch_walk(w, h->persistent_blocks / BLOCKS_PER_CU, h->stream));
+            }
+            HIP_TRY(h, fresh_counter());
+            a.park = last ? 0u : 1u;
+            a.q_out = last ? nullptr : h->park_queue[(r + 1) & 1u];
+            a.q_out_count = last ? nullptr : h->park_counts + r + 1;
+            HIP_TRY(h, launch_render(a, h->stream));
+        }
+    }
     if (n_batch) {
         BlendArgs b{};
         b.image = h->image;

@@ -49,7 +49,10 @@ constexpr uint32_t ITEM_BYTES = 32;
 //        (a quad split into its two triangles, ...).  Its whole traversal is two box tests and the leaves' triangles,
 //        near leaf first: the few-mesh kernels run it as straight-line code with every lane of the wave in step,
 //        no stack and no loop (traverse_flat2), instead of as a forest member or a mesh walk.
-enum : uint32_t { ITEM_TLAS = 1u, ITEM_NEW_XFORM = 2u, ITEM_FOREST = 4u, ITEM_FLAT2 = 8u };
+enum : uint32_t { ITEM_TLAS = 1u, ITEM_NEW_XFORM = 2u, ITEM_FOREST = 4u, ITEM_FLAT2 = 8u,
+                  ITEM_DEFER = 16u,       // the big mesh whose walk a launch with RenderArgs::park != 0 defers (last item)
+                  ITEM_DEFER_CULL = 32u   // ... and its root box provably contains its children's (missing it = missing the mesh)
+};
 // A top-level tree's reference to a mesh (the child index of a tree record whose child count is non-zero; with bit
 // 31 set, an entry of the tree stack): everything a lane needs to enter the mesh -- the mesh's index (the caps allow
 // 400), the absolute index of its root's wide record (<= 1.3 M internal nodes) and whether it is glass (wgsl:376: no
@@ -185,7 +188,30 @@ struct RenderArgs {
     // top_base + top_count - 1 -- the first levels of the biggest mesh, numbered breadth-first at upload
     // -- are copied into LDS by every workgroup (coalesced 16-byte loads) and read from there.
     uint32_t top_base, top_count;
+    // Deferred walks (option "sort_rounds"; scenes with one big mesh, few-mesh kernels).  The walk through a big
+    // mesh is entered by a few lanes of a wave at a time and costs the whole wave its full length.  With park != 0
+    // a render launch does not walk that mesh (its item, ITEM_DEFER, is the last of the mesh loop -- the order of the
+    // loop is free): a lane whose ray can enter it PARKS its pixel -- the pixel's state and the closest-hit record
+    // of the segment so far go to a queue in global memory (park records, below) -- and takes other work.
+    // rt_walk_kernel then walks the big mesh for all parked rays, every lane fetching its next ray as soon as its
+    // walk ends, and the next render launch resumes the parked pixels behind the walk: offer the mesh's hit, finish
+    // the segment, go on until the next entry into the big mesh.  A pixel's operations and their order are those of
+    // the undeferred loop, so the image is the same bit for bit; the last launch of a sequence has park = 0 and
+    // walks what is left inline.
+    uint32_t park;
+    float4* q_in;                 // park records to resume instead of tiles (null: the work items are tiles)
+    const uint32_t* q_in_count;   // their number (written by the launch before)
+    float4* q_out;                // where this launch parks
+    uint32_t* q_out_count;
+    uint32_t defer_mesh, defer_xform;  // the deferred mesh and the mesh whose matrices give its local ray
 };
+// Park record of a pixel: 14 x 16 B, stored in blocks of 64 records, plane by plane (plane p of record i of block b at
+// float4 index (b * PARK_PLANES + p) * 64 + i), so that the lanes of a wave, which hold consecutive records, store and
+// load contiguous kilobytes.  Planes: 0 (x, out_row, rng, j)  1 (seg, fresh, meta, memo[12])  2 (ro, rd.x)
+// 3 (rd.yz, T.xy)  4 (T.zw, light.xy)  5 (light.zw, -, -)  6 total  7-9 memo[0..11]  10 (closest, object, any |
+// inside << 1, sphere dst)  11 (win_u, win_v, win_tri, win_point.x)  12 (win_point.yz, -, -)  13 the walk's result
+// (t, u, v, tri | det sign; tri = ~0: no hit), written by rt_walk_kernel.
+constexpr uint32_t PARK_PLANES = 14;
 
 constexpr uint32_t RT_MAX_BATCH_FRAMES = 32;
 // rt_blend_frames_kernel: image = the accumulation image, scratch = batch frame 0

@@ -572,6 +572,7 @@ struct Hit {
     float u, v;       // texture coordinates
     bool backface;
     uint32_t mat_off; // byte offset of the winner's material in the blob
+    bool suspended;   // deferred walks: the segment stops before the big mesh (the caller parks the pixel)
 };
 
 // world-space hit point and distance of a mesh-local hit at parameter t (wgsl:380-381); m2w =
@@ -663,6 +664,7 @@ DEV Hit isect_finish(const RenderArgs& a, const Isect& I, f3 ro, f3 rd) {
     h.normal = f3{0, 0, 0};
     h.u = h.v = 0.0f;
     h.backface = false;
+    h.suspended = false;
     TIC(t9);
     if (I.any) {
         DIAG(11);
@@ -705,11 +707,12 @@ DEV Hit isect_finish(const RenderArgs& a, const Isect& I, f3 ro, f3 rd) {
 }
 
 // wgsl:353-396 (+ ray_sphere :223-256).
-template <bool LDS, bool STATS, bool TLAS>
+template <bool LDS, bool STATS, bool TLAS, bool PARK = false>
 DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int& node_tests,
-                        int& tri_tests) {
+                        int& tri_tests, Isect& I_parked) {
     // this lane's TLAS stack column sits behind the wave's BVH stack columns
     uint32_t* tstack = stack + stack_dwords(a);
+    bool suspended = false;
     Isect I;
     isect_spheres<LDS>(a, ro, rd, I);
     // meshes (wgsl:369-393), as items: single meshes and top-level trees over mesh root boxes
@@ -813,6 +816,23 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         }
         if constexpr (!TLAS) {
             const float4 hdr = ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16);
+            if (PARK && (kind & ITEM_DEFER) != 0u && a.park != 0u) {
+                // Deferred walk (RenderArgs::park): the segment stops here for the lanes whose ray can enter the
+                // mesh; rt_walk_kernel walks it, the next launch offers its hit and finishes the segment.  A ray
+                // that misses a root box which contains its children's boxes misses the mesh (the monotonicity
+                // argument of root-box culling, finite rays only) and goes on as if it had walked it.
+                flush_pending();
+                bool may_hit = true;
+                if ((kind & ITEM_DEFER_CULL) != 0u) {
+                    const bool finite_ray = rtm::abs_(inv.x) < INF && rtm::abs_(inv.y) < INF && rtm::abs_(inv.z) < INF &&
+                                            rtm::abs_(lo.x) < INF && rtm::abs_(lo.y) < INF && rtm::abs_(lo.z) < INF;
+                    const uint32_t mo = a.lay.mesh_off + ia * MESH_REC_BYTES;
+                    may_hit = !finite_ray || aabb_dist(lo, inv, ld4<LDS>(a, mo + 160), ld4<LDS>(a, mo + 176), INF) < INF;
+                }
+                if (may_hit) suspended = true;
+                else if (STATS) node_tests += 2;  // the shader's two root-level tests (wgsl:322)
+                continue;
+            }
             if (kind & ITEM_FLAT2) {
                 MeshBest b;
                 b.t = INF;
@@ -977,6 +997,13 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         }
     }
     if constexpr (!TLAS) flush_pending();
+    if (PARK && suspended) {
+        I_parked = I;
+        Hit h;
+        h.hit = false;
+        h.suspended = true;
+        return h;
+    }
     return isect_finish<LDS>(a, I, ro, rd);
 }
 
@@ -1292,6 +1319,7 @@ enum : uint32_t {
     STEP_WAIT = 1,      // wants a traversal but the wave voted against one now
     STEP_REUSE = 2,     // memoised primary ray: take its hit from the memo
     STEP_TRAVERSE = 3,  // intersect the scene
+    STEP_RESUME = 4,    // deferred walks: the segment's hit is the parked closest-hit record + the big mesh's walk
 };
 
 template <bool STATS>
@@ -1492,25 +1520,137 @@ DEV bool path_end(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t mod
     return false;
 }
 
-template <bool LDS, bool STATS, bool TLAS>
-DEV bool path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
-                   uint32_t& n_reused_wave, int& node_tests, int& tri_tests) {
-    const uint32_t mode = path_begin<STATS>(a, s, ls, starve);
+// returns PATH_CONTINUE, PATH_PIXEL_DONE (the pixel's last sample ended) or PATH_PARK (the pixel was parked in front
+// of the deferred mesh, RenderArgs::park)
+enum : uint32_t { PATH_CONTINUE = 0, PATH_PIXEL_DONE = 1, PATH_PARK = 2 };
+template <bool TOTAL_LDS>
+DEV void park_store(const RenderArgs& a, uint32_t slot, const PixelState& s, uint32_t* ls, const Isect& I);
+DEV void park_load_hit(const RenderArgs& a, uint32_t slot, Isect& I, CompactHit& walked);
+
+template <bool LDS, bool STATS, bool TLAS, bool PARK = false>
+DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
+                       uint32_t& n_reused_wave, int& node_tests, int& tri_tests, uint32_t resume_slot = 0xffffffffu) {
+    // (a resumed pixel was parked behind path_begin: its segment has begun)
+    const uint32_t mode = PARK && resume_slot != 0xffffffffu ? (uint32_t)STEP_RESUME : path_begin<STATS>(a, s, ls, starve);
     // segments served from the memo, counted per wave (a scalar add): Mrays/s can then be stated for
     // traversed rays as well
     n_reused_wave += (uint32_t)__popcll(__ballot(mode == STEP_REUSE));
-    if (mode == STEP_WAIT) return false;
+    if (mode == STEP_WAIT) return PATH_CONTINUE;
     Hit hit;
     hit.hit = false;
+    hit.suspended = false;
     if (mode == STEP_REUSE) {
         memo_hit_load(a, ls, hit);
     } else if (mode == STEP_TRAVERSE) {
         TIC(t0);
-        hit = intersect_scene<LDS, STATS, TLAS>(a, s.ro, s.rd, stack_of<total_in_lds(LDS)>(ls), node_tests, tri_tests);
+        Isect I;
+        hit = intersect_scene<LDS, STATS, TLAS, PARK>(a, s.ro, s.rd, stack_of<total_in_lds(LDS)>(ls), node_tests, tri_tests, I);
         TOC(t0, 0);
+        if constexpr (PARK && !TLAS) {
+            if (a.park != 0u) {  // (wave-uniform)
+                // park the suspended lanes' pixels: consecutive records, one counter update per wave
+                const unsigned long long here = __ballot(true), parking = __ballot(hit.suspended);
+                if (parking != 0ull) {
+                    uint32_t slot0 = 0;
+                    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(here)) slot0 = atomicAdd(a.q_out_count, (uint32_t)__popcll(parking));
+                    slot0 = __builtin_amdgcn_readlane(slot0, __builtin_ctzll(here));
+                    if (hit.suspended) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(parking >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)parking, 0u));
+                        park_store<total_in_lds(LDS)>(a, slot0 + rank, s, ls, I);
+                        return PATH_PARK;
+                    }
+                }
+            }
+        }
+        memo_hit_store<STATS>(a, s, ls, hit);
+    } else if (PARK && !TLAS && mode == STEP_RESUME) {
+        // behind the deferred mesh's walk: offer the walk's hit (the local ray: the operations of ITEM_NEW_XFORM),
+        // finish the segment
+        Isect I;
+        CompactHit walked;
+        park_load_hit(a, resume_slot, I, walked);
+        if (walked.tri != 0xffffffffu) {
+            const uint32_t xo = a.lay.mesh_off + a.defer_xform * MESH_REC_BYTES;
+            const float4 c0 = ld4<LDS>(a, xo), c1 = ld4<LDS>(a, xo + 16), c2 = ld4<LDS>(a, xo + 32), c3 = ld4<LDS>(a, xo + 48);
+            const f3 lo = mat_cols_xyz(c0, c1, c2, c3, s.ro, 1.0f);
+            const f3 ld = normalize3(mat_cols_xyz(c0, c1, c2, c3, s.rd, 0.0f));
+            f3 whp;
+            float wdst;
+            world_hit<LDS>(a, a.lay.mesh_off + a.defer_mesh * MESH_REC_BYTES + 64u, lo, ld, s.ro, walked.t, whp, wdst);
+            isect_offer(I, a.defer_mesh, walked, whp, wdst);
+        }
+        hit = isect_finish<LDS>(a, I, s.ro, s.rd);
         memo_hit_store<STATS>(a, s, ls, hit);
     }
-    return path_end<LDS, total_in_lds(LDS)>(a, s, ls, mode, hit, n_segments);
+    return path_end<LDS, total_in_lds(LDS)>(a, s, ls, mode, hit, n_segments) ? PATH_PIXEL_DONE : PATH_CONTINUE;
+}
+
+// Park records (rt_device.h): the whole state of a pixel between two segments.
+template <bool TOTAL_LDS>
+DEV void park_store(const RenderArgs& a, uint32_t slot, const PixelState& s, uint32_t* ls, const Isect& I) {
+    float4* q = a.q_out + (size_t)(slot >> 6) * (PARK_PLANES * 64u) + (slot & 63u);
+    auto u = [](uint32_t v) { return __uint_as_float(v); };
+    f4 total = s.total;
+    if constexpr (TOTAL_LDS)
+        total = f4{__uint_as_float(ls[0]), __uint_as_float(ls[64]), __uint_as_float(ls[128]), __uint_as_float(ls[192])};
+    uint32_t m[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.pixel_cache != 0u)
+        with_memo(a, ls, [&](auto pc) {
+            for (uint32_t k = 0; k < 13u; ++k) m[k] = pc[k * 64u];
+        });
+    q[0 * 64] = make_float4(u(s.x), u(s.out_row), u(s.rng), u((uint32_t)s.j));
+    q[1 * 64] = make_float4(u((uint32_t)s.seg), u(s.fresh ? 1u : 0u), u(s.meta), u(m[12]));
+    q[2 * 64] = make_float4(s.ro.x, s.ro.y, s.ro.z, s.rd.x);
+    q[3 * 64] = make_float4(s.rd.y, s.rd.z, s.T.x, s.T.y);
+    q[4 * 64] = make_float4(s.T.z, s.T.w, s.light.x, s.light.y);
+    q[5 * 64] = make_float4(s.light.z, s.light.w, 0.0f, 0.0f);
+    q[6 * 64] = make_float4(total.x, total.y, total.z, total.w);
+    q[7 * 64] = make_float4(u(m[0]), u(m[1]), u(m[2]), u(m[3]));
+    q[8 * 64] = make_float4(u(m[4]), u(m[5]), u(m[6]), u(m[7]));
+    q[9 * 64] = make_float4(u(m[8]), u(m[9]), u(m[10]), u(m[11]));
+    q[10 * 64] = make_float4(I.closest, u((uint32_t)I.object), u((I.any ? 1u : 0u) | (I.s_inside ? 2u : 0u)), I.s_dst);
+    q[11 * 64] = make_float4(I.win_u, I.win_v, u(I.win_tri), I.win_point.x);
+    q[12 * 64] = make_float4(I.win_point.y, I.win_point.z, 0.0f, 0.0f);
+}
+// the closest-hit record of the parked segment and the walk's result
+DEV void park_load_hit(const RenderArgs& a, uint32_t slot, Isect& I, CompactHit& walked) {
+    const float4* q = a.q_in + (size_t)(slot >> 6) * (PARK_PLANES * 64u) + (slot & 63u);
+    const float4 p10 = q[10 * 64], p11 = q[11 * 64], p12 = q[12 * 64], p13 = q[13 * 64];
+    I.closest = p10.x;
+    I.object = (int)fbits(p10.y);
+    I.any = (fbits(p10.z) & 1u) != 0u;
+    I.s_inside = (fbits(p10.z) & 2u) != 0u;
+    I.s_dst = p10.w;
+    I.win_u = p11.x;
+    I.win_v = p11.y;
+    I.win_tri = fbits(p11.z);
+    I.win_point = f3{p11.w, p12.x, p12.y};
+    walked = CompactHit{p13.x, p13.y, p13.z, fbits(p13.w)};
+}
+template <bool TOTAL_LDS>
+DEV void park_load(const RenderArgs& a, uint32_t slot, PixelState& s, uint32_t* ls) {
+    const float4* q = a.q_in + (size_t)(slot >> 6) * (PARK_PLANES * 64u) + (slot & 63u);
+    const float4 p0 = q[0 * 64], p1 = q[1 * 64], p2 = q[2 * 64], p3 = q[3 * 64], p4 = q[4 * 64], p5 = q[5 * 64], p6 = q[6 * 64];
+    s.x = fbits(p0.x); s.out_row = fbits(p0.y); s.rng = fbits(p0.z); s.j = (int32_t)fbits(p0.w);
+    s.seg = (int32_t)fbits(p1.x); s.fresh = fbits(p1.y) != 0u; s.meta = fbits(p1.z);
+    s.ro = f3{p2.x, p2.y, p2.z};
+    s.rd = f3{p2.w, p3.x, p3.y};
+    s.T = f4{p3.z, p3.w, p4.x, p4.y};
+    s.light = f4{p4.z, p4.w, p5.x, p5.y};
+    s.total = f4{p6.x, p6.y, p6.z, p6.w};
+    if constexpr (TOTAL_LDS) {
+        ls[0] = fbits(p6.x); ls[64] = fbits(p6.y); ls[128] = fbits(p6.z); ls[192] = fbits(p6.w);
+    }
+    if (a.pixel_cache != 0u) {
+        const float4 p7 = q[7 * 64], p8 = q[8 * 64], p9 = q[9 * 64];
+        with_memo(a, ls, [&](auto pc) {
+            pc[0 * 64] = fbits(p7.x); pc[1 * 64] = fbits(p7.y); pc[2 * 64] = fbits(p7.z); pc[3 * 64] = fbits(p7.w);
+            pc[4 * 64] = fbits(p8.x); pc[5 * 64] = fbits(p8.y); pc[6 * 64] = fbits(p8.z); pc[7 * 64] = fbits(p8.w);
+            pc[8 * 64] = fbits(p9.x); pc[9 * 64] = fbits(p9.y); pc[10 * 64] = fbits(p9.z); pc[11 * 64] = fbits(p9.w);
+            pc[12 * 64] = fbits(p1.w);
+        });
+    }
 }
 
 // wgsl:498 + 154-161
@@ -1563,7 +1703,7 @@ DEV void tile_cost_add(const RenderArgs& a, uint32_t* tbl, const PixelState& s) 
 
 template <bool STATS>
 DEV void flush_counters(const RenderArgs& a, uint32_t n_segments, uint32_t n_reused_wave, int node_tests, int tri_tests) {
-    if (a.counters) {
+    if (a.counters && __ballot(n_segments != 0u || (STATS && (node_tests | tri_tests) != 0)) != 0ull) {
         atomicAdd(&a.counters->segments, (unsigned long long)n_segments);
         if (n_reused_wave != 0u && (threadIdx.x & 63u) == 0u) atomicAdd(&a.counters->reused, (unsigned long long)n_reused_wave);
         if (STATS) {
@@ -1594,7 +1734,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     uint32_t n_segments = 0, n_reused_wave = 0;
     int node_tests = 0, tri_tests = 0;
     while (active) {
-        if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, n_reused_wave, node_tests, tri_tests)) active = false;
+        if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, n_reused_wave, node_tests, tri_tests) == PATH_PIXEL_DONE)
+            active = false;
     }
     if (valid) pixel_finish<total_in_lds(LDS)>(a, s, ls);
     if (a.tile_cost && tile_ok) {  // one store per wave: the tile's rays
@@ -1611,7 +1752,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
 // wave's current tile, so the wave stays full until the frame runs out.  The
 // per-pixel RNG stream depends only on the pixel's coordinates, so the image
 // does not depend on which lane rendered which pixel.
-template <bool LDS, bool STATS, bool TLAS>
+template <bool LDS, bool STATS, bool TLAS, bool PARK>
 __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persistent_kernel(const RenderArgs a) {
 #if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
     const unsigned long long t_wave_start = __builtin_amdgcn_s_memrealtime();
@@ -1627,8 +1768,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
     uint32_t pool_base = 0, pool_left = 0;  // wave-uniform: pixels left in the current tile
     uint32_t pool_frame = 0;                // wave-uniform: the current tile's frame inside a frame batch
     uint32_t pool_txy = 0;                  // wave-uniform: the current tile's column | (local) row << 16, divided out once per pull
-    const uint32_t n_items = n_tiles * (a.batch_frames ? a.batch_frames : 1u);  // (frame, tile) pairs, frame-major
-    bool exhausted = false;
+    // work items: (frame, tile) pairs, or -- a later launch of the sorting rounds -- blocks of 64 park records
+    const bool resuming = PARK && a.q_in != nullptr;  // (PARK: the instantiations the deferred-walk sequences launch)
+    const uint32_t n_parked = resuming ? *a.q_in_count : 0u;
+    const uint32_t n_items = resuming ? (n_parked + 63u) >> 6 : n_tiles * (a.batch_frames ? a.batch_frames : 1u);
+    // (a launch with fewer items than waves -- the later rounds of a deferred-walk sequence -- would otherwise consist
+    // of thousands of pulls queueing up on one address: the waves beyond the items never pull)
+    bool exhausted = PARK && blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6) >= n_items;
     PixelState s;
     pixel_begin<total_in_lds(LDS)>(a, camera_consts(a), s, ls, 0, 0, 0);
     bool active = false;
@@ -1639,6 +1785,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
     if (lane < COST_SLOTS * 3u) cost_tbl[lane] = 0u;
     uint32_t starve = 0;
     uint32_t pull_seq = 0;
+    uint32_t resume_slot = 0xffffffffu;  // (PARK) the park record this lane's pixel was just resumed from
 
     for (;;) {
         const unsigned long long idle = __ballot(!active);
@@ -1648,8 +1795,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                 uint32_t t = 0;
                 if (lane == 0) t = atomicAdd(a.work_counter, 1u);
                 t = __builtin_amdgcn_readfirstlane(t);
+                pull_seq += 1;
                 if (t >= n_items) {
                     exhausted = true;
+                } else if (resuming) {
+                    pool_base = t * 64u;
+                    pool_left = n_parked - pool_base < 64u ? n_parked - pool_base : 64u;
                 } else {
                     pool_frame = 0u;
                     if (a.batch_frames != 0u) {
@@ -1669,7 +1820,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                         const uint32_t ty = t / a.tiles_x;
                         pool_txy = (t - ty * a.tiles_x) | (ty << 16);
                     }
-                    pull_seq += 1;
                     // (a batch records the costs of its first frame)
                     if (a.tile_cost && lane == 0 && pool_frame == 0u) tile_cost_pull(a, cost_tbl, pull_seq & (COST_SLOTS - 1u), t);
                 }
@@ -1677,7 +1827,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
             if (pool_left != 0) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                if (!active && rank < pool_left) {
+                if (!active && rank < pool_left && resuming) {
+                    if constexpr (PARK) {  // resume a parked pixel (path_step finishes its segment)
+                        resume_slot = pool_base + rank;
+                        park_load<total_in_lds(LDS)>(a, resume_slot, s, ls);
+                        active = true;
+                    }
+                } else if (!active && rank < pool_left) {
                     const uint32_t q = pool_base + rank;
                     ColdArgs& ca = cold_args();
                     const PixelCoord px = pixel_at(ca, pool_txy & 0xffffu, pool_txy >> 16, q & 63u);  // (q >> 6 is the pulled tile)
@@ -1707,14 +1863,18 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
             continue;
         }
         TIC(t15);
+        uint32_t step = PATH_CONTINUE;
         if (active) {
-            if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, n_reused_wave, node_tests, tri_tests)) {
+            step = path_step<LDS, STATS, TLAS, PARK>(a, s, ls, starve, n_segments, n_reused_wave, node_tests, tri_tests, resume_slot);
+            resume_slot = 0xffffffffu;
+            if (step == PATH_PIXEL_DONE) {
                 DIAG(16);
                 pixel_finish<total_in_lds(LDS)>(cold_args(), s, ls);
                 if (a.tile_cost && (s.meta >> 19) == 0u) tile_cost_add(a, cost_tbl, s);
                 active = false;
             }
         }
+        if (step == PATH_PARK) active = false;  // (parked by path_step)
         TOC(t15, 15);
     }
     flush_counters<STATS>(a, n_segments, n_reused_wave, node_tests, tri_tests);
@@ -1730,6 +1890,125 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         }
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// Deferred walks (RenderArgs::park): the big mesh's walk for every parked ray.  A record's ray is taken to the
+// mesh's local space with the operations of ITEM_NEW_XFORM and walked exactly as traverse_mesh walks it (far child
+// pushed, near child next, entries popped without re-testing, a leaf's triangles in order); the closest triangle hit
+// goes back into the record (plane 13).  A lane takes its next ray as soon as its walk ends, so the node-visit and
+// triangle passes stay populated whatever the lengths of the individual walks.
+// ---------------------------------------------------------------------------
+template <bool STATS>
+__global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* stack = reinterpret_cast<uint32_t*>(lds_mem) + (threadIdx.x >> 6) * stack_dwords(a) + lane;
+    const LaneStack st{stack, a.stack_wide != 0u};
+    const uint32_t n = *a.q_in_count;
+    const uint32_t xo = a.lay.mesh_off + a.defer_xform * MESH_REC_BYTES;
+    const float4 c0 = ld4<false>(a, xo), c1 = ld4<false>(a, xo + 16), c2 = ld4<false>(a, xo + 32), c3 = ld4<false>(a, xo + 48);
+    const float4 hdr = ld4<false>(a, a.lay.mesh_off + a.defer_mesh * MESH_REC_BYTES + 128);
+    const uint32_t root = fbits(hdr.y);  // (an internal root: the host defers no other mesh)
+    const bool cull = (fbits(hdr.x) & DMESH_GLASS) == 0u;
+    const uint32_t tri0 = a.lay.tri_off;
+    uint32_t pool_base = 0, pool_left = 0;  // wave-uniform: records reserved by this wave
+    bool exhausted = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 256u >= n;  // (waves beyond the work never pull)
+    uint32_t slot = 0, cur = 0, cur_count = 0, sp = 0;
+    bool have = false;
+    f3 lo{0, 0, 0}, ld{0, 0, 0}, inv{0, 0, 0};
+    MeshBest b;
+    b.t = INF;
+    b.tri = 0xffffffffu;
+    b.u = b.v = 0.0f;
+    int node_tests = 0, tri_tests = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        if (idle != 0ull && !exhausted) {
+            if (pool_left == 0) {
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(a.work_counter, 256u);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t >= n) {
+                    exhausted = true;
+                } else {
+                    pool_base = t;
+                    pool_left = n - t < 256u ? n - t : 256u;
+                }
+            }
+            if (pool_left != 0) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (!have && rank < pool_left) {
+                    slot = pool_base + rank;
+                    const float4* q = a.q_in + (size_t)(slot >> 6) * (PARK_PLANES * 64u) + (slot & 63u);
+                    const float4 p2 = q[2 * 64], p3 = q[3 * 64];
+                    lo = mat_cols_xyz(c0, c1, c2, c3, f3{p2.x, p2.y, p2.z}, 1.0f);
+                    ld = normalize3(mat_cols_xyz(c0, c1, c2, c3, f3{p2.w, p3.x, p3.y}, 0.0f));
+                    inv = f3{1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z};
+                    cur = root;
+                    cur_count = 0;
+                    sp = 0;
+                    b.t = INF;
+                    b.tri = 0xffffffffu;
+                    b.u = b.v = 0.0f;
+                    have = true;
+                }
+                const uint32_t n_idle = (uint32_t)__popcll(idle);
+                const uint32_t taken = n_idle < pool_left ? n_idle : pool_left;
+                pool_base += taken;
+                pool_left -= taken;
+            }
+        }
+        if (__ballot(have) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        const bool walking = have;
+        while (have && cur_count == 0) {  // descend to the next leaf (traverse_mesh's step)
+            float4 q0, q1, q2, q3;
+            load_wide<false>(a, cur, q0, q1, q2, q3);
+            const float da = aabb_dist(lo, inv, q0, q1, b.t);
+            const float db = aabb_dist(lo, inv, q2, q3, b.t);
+            if (STATS) node_tests += 2;
+            const bool left_closer = da < db;
+            const float near_d = left_closer ? da : db, far_d = left_closer ? db : da;
+            const uint32_t near_i = fbits(left_closer ? q1.z : q3.z), near_c = fbits(left_closer ? q1.w : q3.w);
+            const uint32_t far_i = fbits(left_closer ? q3.z : q1.z), far_c = fbits(left_closer ? q3.w : q1.w);
+            if (far_d < b.t) {
+                stack_put(st, sp, far_i, far_c);
+                ++sp;
+            }
+            if (near_d < b.t) {
+                cur = near_i;
+                cur_count = near_c;
+            } else if (sp == 0) {
+                have = false;
+            } else {
+                --sp;
+                stack_get(st, sp, cur, cur_count);
+            }
+        }
+        if (have) {  // a leaf
+            if (STATS) tri_tests += (int)cur_count;
+            for (uint32_t j = 0; j < cur_count; ++j) {
+                const uint32_t t = tri0 + (cur + j) * TRI_ISECT_BYTES;
+                tri_test<8>(lo, ld, ld4<false>(a, t), ld4<false>(a, t + 16), ld4<false>(a, t + 32), cull, cur + j, b);
+            }
+            if (sp == 0) {
+                have = false;
+            } else {
+                --sp;
+                stack_get(st, sp, cur, cur_count);
+            }
+        }
+        if (walking && !have) {  // the walk ended: its result goes back into the record
+            float4* q = a.q_in + (size_t)(slot >> 6) * (PARK_PLANES * 64u) + (slot & 63u);
+            q[13 * 64] = make_float4(b.t, b.u, b.v, __uint_as_float(b.tri));
+        }
+    }
+    if (STATS && a.counters && __ballot((node_tests | tri_tests) != 0) != 0ull) {
+        atomicAdd(&a.counters->node_tests, (unsigned long long)node_tests);
+        atomicAdd(&a.counters->triangle_tests, (unsigned long long)tri_tests);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1752,7 +2031,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rt_debug_kernel(const RenderArg
     const f3 focus_point = mat_xyz(c2w, local_focus, 1.0f);
     f3 rd = normalize3(focus_point - cam_origin);
     int s0 = 0, s1 = 0;
-    Hit hit = intersect_scene<LDS, true, TLAS>(a, cam_origin, rd, stack, s0, s1);
+    Isect isect;
+    Hit hit = intersect_scene<LDS, true, TLAS>(a, cam_origin, rd, stack, s0, s1, isect);
     const float scale = (float)a.params.debug_scale;
     f4 out{1.0f, 0.0f, 1.0f, 1.0f};
     switch (a.params.debug_flag) {
@@ -1961,8 +2241,14 @@ static void launch_variant(const RenderArgs& a, uint32_t ntiles, size_t lds, hip
     } else {
         uint32_t blocks = a.persistent_blocks < tile_blocks ? a.persistent_blocks : tile_blocks;
         if (blocks == 0) blocks = 1;
-        if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS>, blocks, lds, stream, a);
-        else launch_k(rt_render_persistent_kernel<LDS, false, TLAS>, blocks, lds, stream, a);
+        const bool park = !TLAS && (a.park != 0u || a.q_in != nullptr);  // a launch of a deferred-walk sequence
+        if (park) {
+            if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS, !TLAS>, blocks, lds, stream, a);
+            else launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS>, blocks, lds, stream, a);
+        } else {
+            if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS, false>, blocks, lds, stream, a);
+            else launch_k(rt_render_persistent_kernel<LDS, false, TLAS, false>, blocks, lds, stream, a);
+        }
     }
 }
 
@@ -1979,6 +2265,20 @@ hipError_t launch_render(const RenderArgs& a, hipStream_t stream) {
     } else {
         if (tlas) launch_variant<false, true>(a, ntiles, lds, stream);
         else launch_variant<false, false>(a, ntiles, lds, stream);
+    }
+    return hipGetLastError();
+}
+
+// the deferred mesh's walk for the records of a.q_in (persistent grid: 8 workgroups per CU)
+hipError_t launch_walk(const RenderArgs& a, uint32_t compute_units, hipStream_t stream) {
+    const size_t lds = (size_t)(a.stack_entries ? a.stack_entries : 1u) * (a.stack_wide ? 128u : 64u) * sizeof(uint32_t) * WAVES_PER_BLOCK;
+    const uint32_t blocks = compute_units * 8u;
+    if (a.count_tests) {
+        if (lds > 64u * 1024u) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rt_walk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(rt_walk_kernel<true>, dim3(blocks), dim3(BLOCK_THREADS), lds, stream, a);
+    } else {
+        if (lds > 64u * 1024u) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rt_walk_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(rt_walk_kernel<false>, dim3(blocks), dim3(BLOCK_THREADS), lds, stream, a);
     }
     return hipGetLastError();
 }
