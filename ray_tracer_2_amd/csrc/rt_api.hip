@@ -61,7 +61,11 @@ struct rt_handle {
     // deferred walks (RenderArgs::park): the deferred mesh found at upload, the two park queues, their counters
     bool have_defer = false;
     uint32_t defer_mesh = 0, defer_xform = 0;
-    int sort_rounds = 0;  // option "sort_rounds": render launches that park, after which one launch runs what is left (0 = off)
+    // option "sort_rounds": walk-and-resume rounds of a deferred-walk sequence; 0 = off, -1 (default) = automatic: 6
+    // rounds for batches of >= 24 frames, 4 for >= 16, off below (a round has a fixed cost -- its longest chain of
+    // dependent segments -- that only a big launch amortises) and off when the two park queues (224 B per pixel and
+    // frame of the batch, each) would take more than a quarter of the free device memory
+    int sort_rounds = -1;
     float4* park_queue[2] = {nullptr, nullptr};
     size_t park_capacity = 0;  // records per queue
     uint32_t* park_counts = nullptr;
@@ -901,7 +905,7 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "lds_scene") {
         h->force_global = value ? 0 : 1;
     } else if (n == "sort_rounds") {
-        if (value < 0 || value > 64) return fail(h, RT_ERR_INVALID_ARGUMENT, "sort_rounds must be 0 (off) .. 64");
+        if (value < -1 || value > 64) return fail(h, RT_ERR_INVALID_ARGUMENT, "sort_rounds must be -1 (automatic), 0 (off) or 1 .. 64");
         h->sort_rounds = value;
     } else if (n == "lds_top") {
         if (value < -1 || value > 2048) return fail(h, RT_ERR_INVALID_ARGUMENT, "lds_top must be -1 (auto), 0 (off) or a record count <= 2048");
@@ -1093,7 +1097,17 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.tile_order = nullptr;
     a.tile_cost = nullptr;
     // deferred walks (RenderArgs::park): path-trace frames of a few-mesh scene with one big mesh, persistent kernel
-    const bool rounds = h->sort_rounds > 0 && h->have_defer && a.many_mesh == 0 && a.kernel_variant == 0 && params->debug_flag == 0 &&
+    uint32_t n_rounds = h->sort_rounds > 0 ? (uint32_t)h->sort_rounds : 0u;
+    const size_t park_records = (size_t)need_texels * (n_batch ? n_batch : 1u);
+    const size_t park_bytes = ((park_records + 63) / 64) * (size_t)PARK_PLANES * 64u * sizeof(float4);  // per queue
+    if (h->sort_rounds < 0 && h->have_defer) {
+        n_rounds = n_batch >= 24 ? 6u : n_batch >= 16 ? 4u : 0u;
+        if (n_rounds && h->park_capacity < park_records) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || 2 * park_bytes > free_b / 4) n_rounds = 0;
+        }
+    }
+    const bool rounds = n_rounds > 0 && h->have_defer && a.many_mesh == 0 && a.kernel_variant == 0 && params->debug_flag == 0 &&
                         params->rays_per_pixel > 0;
     if (h->tile_feedback && params->debug_flag == 0 && n_tiles <= h->tile_capacity && n_tiles > 0 && a.kernel_variant == 0) {
         const bool same_shape = h->history_valid && h->hist_w == params->width && h->hist_h == params->height &&
@@ -1152,16 +1166,14 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         // after round, rt_walk_kernel walks the mesh for the parked rays and a render launch resumes those pixels
         // (parking them again at their next entry); the last render launch does not park: it walks what is left
         // inline.  Everything is ordered on the stream; a launch whose queue is empty ends at once.
-        const size_t cap = (size_t)need_texels * (n_batch ? n_batch : 1u);
-        if (h->park_capacity < cap) {
+        if (h->park_capacity < park_records) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             free_dev(h->park_queue[0]);
             free_dev(h->park_queue[1]);
             h->park_capacity = 0;
-            const size_t bytes = ((cap + 63) / 64) * (size_t)PARK_PLANES * 64u * sizeof(float4);
-            HIP_TRY(h, hipMalloc((void**)&h->park_queue[0], bytes));
-            HIP_TRY(h, hipMalloc((void**)&h->park_queue[1], bytes));
-            h->park_capacity = cap;
+            HIP_TRY(h, hipMalloc((void**)&h->park_queue[0], park_bytes));
+            HIP_TRY(h, hipMalloc((void**)&h->park_queue[1], park_bytes));
+            h->park_capacity = park_records;
         }
         if (!h->park_counts) HIP_TRY(h, hipMalloc((void**)&h->park_counts, 72 * sizeof(uint32_t)));
         HIP_TRY(h, hipMemsetAsync(h->park_counts, 0, 72 * sizeof(uint32_t), h->stream));
@@ -1176,7 +1188,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             a.work_counter = h->work_counters + h->work_slot;
             return hipSuccess;
         };
-        const uint32_t R = (uint32_t)h->sort_rounds;
+        const uint32_t R = n_rounds;
         a.park = 1;
         a.q_in = nullptr;
         a.q_in_count = nullptr;

@@ -407,6 +407,63 @@ def test_config3_dragon_standin(rt, oracle, tracer, dragon_arrays):
         assert same(tracer.read_image(256, 144), ref), dbg
 
 
+def test_deferred_walks_do_not_change_the_bits(rt, oracle, tracer, dragon_arrays):
+    """Option sort_rounds (deferred walks, rt_device.h RenderArgs::park) on the config 3 stand-in: pixels parked in
+    front of the big mesh, the mesh walked by rt_walk_kernel, pixels resumed -- image, segment count and the
+    node / triangle test counters are those of the plain kernels and of the oracle, whatever the number of
+    rounds (1: nearly everything is left to the last launch ... 20: the queues run empty), for single frames,
+    batches, the automatic setting, and strips."""
+    a = dragon_arrays
+    W, H = 240, 135
+    tracer.load_scene(a)
+    p = rt.make_params(W, H, 4, 4, skybox=1, frames=0)
+    ref1, st1 = oracle.render(p, a)
+    acc = np.zeros((H, W, 4), np.float32)
+    for f in range(3):
+        p.frames = f
+        acc, _ = oracle.render(p, a, image=acc)
+    p.frames = 0
+    try:
+        for counters in (False, True):
+            tracer.set_counters(counters)
+            for rounds in (1, 2, 5, 20):
+                tracer.set_option("sort_rounds", rounds)
+                tracer.write_image(np.zeros((H, W, 4), np.float32))
+                tracer.reset_timing()
+                tracer.render(p)
+                s = tracer.stats()
+                assert same(tracer.read_image(W, H), ref1), (counters, rounds)
+                assert s.segments == st1.segments
+                if counters:
+                    assert (s.node_tests, s.triangle_tests) == (st1.node_tests, st1.triangle_tests), rounds
+                tracer.write_image(np.zeros((H, W, 4), np.float32))
+                tracer.render_frames(p, 3)
+                assert same(tracer.read_image(W, H), acc), (counters, rounds, "batch")
+        tracer.set_counters(False)
+        # the automatic setting engages at 16 frames per launch: against the plain kernels
+        tracer.set_option("batch_frames", 16)
+        outs = []
+        for rounds in (0, -1):
+            tracer.set_option("sort_rounds", rounds)
+            tracer.write_image(np.zeros((H, W, 4), np.float32))
+            tracer.render_frames(p, 16)
+            outs.append(tracer.read_image(W, H).copy())
+        assert same(outs[0], outs[1])
+        # strips: every rank of 3, with and without
+        for rank in range(3):
+            outs = []
+            for rounds in (0, 3):
+                tracer.set_option("sort_rounds", rounds)
+                tracer.write_image(np.zeros((H, W, 4), np.float32))
+                tracer.render_strips_frames(p, 3, rank, 3)
+                outs.append(tracer.read_image(W, H).copy())
+            assert same(outs[0], outs[1]), rank
+    finally:
+        tracer.set_counters(False)
+        tracer.set_option("sort_rounds", -1)
+        tracer.set_option("batch_frames", 16)
+
+
 def deep_chain_scene(rt, cornell, levels=36, trap=31):
     """A hand-built chain BVH `levels` deep.  Levels 0..trap-1: the leaf is a far triangle and
     the other child (the rest of the chain) is nearer, so every level leaves a pending far entry
