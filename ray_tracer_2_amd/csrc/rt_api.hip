@@ -60,11 +60,12 @@ struct rt_handle {
     size_t batch_scratch_texels = 0;
     // deferred walks (RenderArgs::park): the deferred mesh found at upload, the two park queues, their counters
     bool have_defer = false;
-    uint32_t defer_mesh = 0, defer_xform = 0;
-    // option "sort_rounds": walk-and-resume rounds of a deferred-walk sequence; 0 = off, -1 (default) = automatic: 6
-    // rounds for batches of >= 24 frames, 4 for >= 16, off below (a round has a fixed cost -- its longest chain of
-    // dependent segments -- that only a big launch amortises) and off when the two park queues (224 B per pixel and
-    // frame of the batch, each) would take more than a quarter of the free device memory
+    uint32_t defer_mesh = 0, defer_xform = 0, defer_internal = 0;  // (internal nodes of its BVH)
+    // option "sort_rounds": walk-and-resume rounds of a deferred-walk sequence; 0 = off, -1 (default) = automatic: by
+    // the work of the launch in units of one 1920 x 1080 frame at 16 samples per pixel and the size of the big mesh
+    // (render_impl; none below 8 units, or 2 for a mesh of 400 k internal nodes and more: a round has a fixed cost, its
+    // longest chain of dependent segments, that only a big launch amortises) -- and off when the two park queues (224 B per pixel and frame of the
+    // batch, each) would take more than a quarter of the free device memory
     int sort_rounds = -1;
     float4* park_queue[2] = {nullptr, nullptr};
     size_t park_capacity = 0;  // records per queue
@@ -497,9 +498,11 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         struct ForestEntry { float4 q[3]; };
         std::vector<ForestEntry> forest_entries;
         uint32_t tlas_depth = 0;
-        auto root_box_ok = [&](uint32_t i) {
+        // (root_box_contains: the root box provably contains its children's boxes; root_box_ok: ... and the mesh is
+        // walked with the ordinary stack)
+        auto root_box_contains = [&](uint32_t i) {
             const rt_node* mn = nodes + meshes[i].node_offset;
-            if (mn[0].count > 0 || deep[i]) return false;
+            if (mn[0].count > 0) return false;
             const rt_node &ca = mn[mn[0].left], &cb = mn[mn[0].right];
             for (int k = 0; k < 3; ++k) {
                 const float lo_k = ca.aabb_min[k] < cb.aabb_min[k] ? ca.aabb_min[k] : cb.aabb_min[k];
@@ -510,6 +513,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             }
             return true;
         };
+        auto root_box_ok = [&](uint32_t i) { return !deep[i] && root_box_contains(i); };
         // (a tree's reference to a mesh has 9 bits for the mesh and 21 for its root record, rt_device.h)
         auto tree_ok = [&](uint32_t i) { return root_box_ok(i) && i <= TLAS_REF_MESH_MASK && root_idx[i] <= TLAS_REF_ROOT_MASK; };
         struct Box { float lo[3], hi[3]; };
@@ -671,11 +675,11 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         const bool has_tlas = !tlas.empty();
 
         // ---- the deferred mesh (RenderArgs::park) ----------------------------------------------
-        // The biggest single-mesh item of a few-mesh scene with a real BVH (not the shader's literal-stack kind):
+        // The biggest single-mesh item of a few-mesh scene with a real BVH:
         // its item goes to the end of the mesh loop (the loop's order is free), where a launch can stop in front
         // of it.
         bool have_defer = false;
-        uint32_t defer_mesh = 0, defer_xform = 0;
+        uint32_t defer_mesh = 0, defer_xform = 0, defer_internal = 0;
         if (!any_tlas && n_meshes < 16) {
             size_t best_k = items.size();
             uint32_t best_big = 0;
@@ -683,7 +687,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 const Item& it = items[k];
                 if (it.kind & (ITEM_TLAS | ITEM_FOREST | ITEM_FLAT2)) continue;
                 const uint32_t mi = it.a;
-                if (root_count[mi] != 0 || deep[mi]) continue;
+                if (root_count[mi] != 0) continue;
                 const uint32_t internal = (mi + 1 < n_meshes ? wide_base[mi + 1] : (uint32_t)wide.size()) - wide_base[mi];
                 if (internal >= 1024 && internal > best_big) { best_big = internal; best_k = k; }
             }
@@ -692,11 +696,12 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 items.erase(items.begin() + (std::ptrdiff_t)best_k);
                 // (the item that followed it in the same local space now opens that space)
                 if ((d.kind & ITEM_NEW_XFORM) && best_k < items.size() && !(items[best_k].kind & ITEM_NEW_XFORM)) items[best_k].kind |= ITEM_NEW_XFORM;
-                d.kind |= ITEM_NEW_XFORM | ITEM_DEFER | (root_box_ok(d.a) ? ITEM_DEFER_CULL : 0u);
+                d.kind |= ITEM_NEW_XFORM | ITEM_DEFER | (root_box_contains(d.a) ? ITEM_DEFER_CULL : 0u);
                 items.push_back(d);
                 have_defer = true;
                 defer_mesh = d.a;
                 defer_xform = d.b;
+                defer_internal = best_big;
             }
         }
 
@@ -815,6 +820,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->have_defer = have_defer;
         h->defer_mesh = defer_mesh;
         h->defer_xform = defer_xform;
+        h->defer_internal = defer_internal;
         // LDS residency: blob + the four waves' stacks, cost tables and lane state within the
         // per-workgroup budget (the primary-ray memo goes to LDS only if it still fits, see render_impl)
         uint64_t stacks = ((uint64_t)h->stack_entries * (h->stack_wide ? 128u : 64u) + (uint64_t)h->tlas_entries * 64u) * sizeof(uint32_t) * WAVES_PER_BLOCK +
@@ -1101,7 +1107,14 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     const size_t park_records = (size_t)need_texels * (n_batch ? n_batch : 1u);
     const size_t park_bytes = ((park_records + 63) / 64) * (size_t)PARK_PLANES * 64u * sizeof(float4);  // per queue
     if (h->sort_rounds < 0 && h->have_defer) {
-        n_rounds = n_batch >= 24 ? 6u : n_batch >= 16 ? 4u : 0u;
+        // (work of the launch in units of one 1920 x 1080 frame at 16 samples per pixel)
+        const double units = (double)park_records * (double)(params->rays_per_pixel > 0 ? params->rays_per_pixel : 0) / (1920.0 * 1080.0 * 16.0);
+        // (tuned on the config 3 and config 5 stand-ins: the longer the walks -- the bigger the mesh's BVH --, the
+        // earlier a round pays for its fixed cost)
+        if (h->defer_internal >= 400000u)
+            n_rounds = units >= 48.0 ? 12u : units >= 24.0 ? 8u : units >= 12.0 ? 4u : units >= 4.0 ? 3u : units >= 2.0 ? 2u : 0u;
+        else
+            n_rounds = units >= 24.0 ? 6u : units >= 12.0 ? 4u : units >= 8.0 ? 3u : 0u;
         if (n_rounds && h->park_capacity < park_records) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || 2 * park_bytes > free_b / 4) n_rounds = 0;

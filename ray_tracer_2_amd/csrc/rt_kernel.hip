@@ -1910,6 +1910,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderA
     const float4 hdr = ld4<false>(a, a.lay.mesh_off + a.defer_mesh * MESH_REC_BYTES + 128);
     const uint32_t root = fbits(hdr.y);  // (an internal root: the host defers no other mesh)
     const bool cull = (fbits(hdr.x) & DMESH_GLASS) == 0u;
+    const bool deep = (fbits(hdr.x) & DMESH_DEEP) != 0u;  // BVH of height >= 32: the shader's literal, clamped stack
     const uint32_t tri0 = a.lay.tri_off;
     uint32_t pool_base = 0, pool_left = 0;  // wave-uniform: records reserved by this wave
     bool exhausted = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 256u >= n;  // (waves beyond the work never pull)
@@ -1963,6 +1964,42 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderA
             continue;
         }
         const bool walking = have;
+        if (deep) {
+            // traverse_mesh's literal walk (wgsl:297-333 with naga's index clamping), one stack entry per trip;
+            // here sp is the shader's stack_index and the entry in hand is always the popped one
+            auto slot_of = [](uint32_t i) { return i < RT_BVH_STACK ? i : RT_BVH_STACK - 1u; };
+            if (have) {
+                if (cur_count > 0) {
+                    if (STATS) tri_tests += (int)cur_count;
+                    for (uint32_t j = 0; j < cur_count; ++j) {
+                        const uint32_t t = tri0 + (cur + j) * TRI_ISECT_BYTES;
+                        tri_test<8>(lo, ld, ld4<false>(a, t), ld4<false>(a, t + 16), ld4<false>(a, t + 32), cull, cur + j, b);
+                    }
+                } else {
+                    float4 q0, q1, q2, q3;
+                    load_wide<false>(a, cur, q0, q1, q2, q3);
+                    const float da = aabb_dist(lo, inv, q0, q1, b.t);
+                    const float db = aabb_dist(lo, inv, q2, q3, b.t);
+                    if (STATS) node_tests += 2;
+                    const bool left_closer = da < db;
+                    const float near_d = left_closer ? da : db, far_d = left_closer ? db : da;
+                    if (far_d < b.t) {
+                        stack_put(st, slot_of(sp), fbits(left_closer ? q3.z : q1.z), fbits(left_closer ? q3.w : q1.w));
+                        sp += 1;
+                    }
+                    if (near_d < b.t) {
+                        stack_put(st, slot_of(sp), fbits(left_closer ? q1.z : q3.z), fbits(left_closer ? q1.w : q3.w));
+                        sp += 1;
+                    }
+                }
+                if (sp == 0) {
+                    have = false;
+                } else {
+                    sp -= 1;
+                    stack_get(st, slot_of(sp), cur, cur_count);
+                }
+            }
+        } else {
         while (have && cur_count == 0) {  // descend to the next leaf (traverse_mesh's step)
             float4 q0, q1, q2, q3;
             load_wide<false>(a, cur, q0, q1, q2, q3);
@@ -1999,6 +2036,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderA
                 --sp;
                 stack_get(st, sp, cur, cur_count);
             }
+        }
         }
         if (walking && !have) {  // the walk ended: its result goes back into the record
             float4* q = a.q_in + (size_t)(slot >> 6) * (PARK_PLANES * 64u) + (slot & 63u);

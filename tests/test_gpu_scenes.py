@@ -440,13 +440,15 @@ def test_deferred_walks_do_not_change_the_bits(rt, oracle, tracer, dragon_arrays
                 tracer.render_frames(p, 3)
                 assert same(tracer.read_image(W, H), acc), (counters, rounds, "batch")
         tracer.set_counters(False)
-        # the automatic setting engages at 16 frames per launch: against the plain kernels
-        tracer.set_option("batch_frames", 16)
+        # the automatic setting (engages from eight 1920 x 1080 x 16 spp frames' worth of paths per launch: here 32
+        # frames of 240 x 135 at 256 spp): against the plain kernels
+        tracer.set_option("batch_frames", 32)
+        p64 = rt.make_params(W, H, 4, 256, skybox=1, frames=0)
         outs = []
         for rounds in (0, -1):
             tracer.set_option("sort_rounds", rounds)
             tracer.write_image(np.zeros((H, W, 4), np.float32))
-            tracer.render_frames(p, 16)
+            tracer.render_frames(p64, 32)
             outs.append(tracer.read_image(W, H).copy())
         assert same(outs[0], outs[1])
         # strips: every rank of 3, with and without
@@ -551,6 +553,16 @@ def test_config5_geometry_standin(rt, oracle, tracer):
     ref, st = oracle.render(p, a)
     assert same(gpu, ref)
     assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests)
+    # deferred walks through the literal-stack mesh (rt_walk_kernel's clamped-stack mode): same image, same counters
+    for rounds in (1, 4):
+        big.set_option("sort_rounds", rounds)
+        big.write_image(np.zeros((90, 160, 4), np.float32))
+        big.reset_timing()
+        big.render(p)
+        s = big.stats()
+        assert same(big.read_image(160, 90), ref), rounds
+        assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests), rounds
+    big.set_option("sort_rounds", -1)
     # a 4K frame fits and runs (config 5's 3840x2160)
     big.set_counters(False)
     big.render(rt.make_params(3840, 2160, 8, 1, skybox=1, frames=0))
