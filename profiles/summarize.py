@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--note", default="")
     ap.add_argument("--demand-json", default="", help="tools/bench_scene.py BS_JSON output: demand bytes per segment from the stats counters")
     ap.add_argument("--no-latest", action="store_true", help="do not rewrite profiles/latest_traffic.json (not the headline config)")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="frames rendered by the whole run (warm-up included): adds a section with the sums over ALL render / walk / "
+                         "blend launches per frame -- for deferred-walk sequences, where a batch is many launches")
     args = ap.parse_args()
     d = args.dir
     tag = os.path.basename(d.rstrip("/")).replace("prof_", "")
@@ -130,6 +133,41 @@ def main():
             rate = agg["SQ_INSTS_VALU"] / dur(steady) / 1e9
             lines.append(f"VALU issue: {rate:.0f} G wave-instructions/s = {rate / (simds * clk / 2):.2f} of the guide's peak "
                          f"(one wave64 instruction per 2 cycles per SIMD x {simds} SIMDs x {clk:.2f} GHz = {simds * clk / 2:.0f} G/s)")
+    if args.total_frames:
+        F = args.total_frames
+        fam = lambda name: "walk" if "rt_walk" in name else "blend" if "rt_blend" in name else "render" if "rt_render" in name else None
+        lines.append("")
+        lines.append(f"== whole run: sums over all render / walk / blend launches, per frame ({F} frames incl. warm-up) ==")
+        tsum = collections.Counter()
+        nl = collections.Counter()
+        for r in trace:
+            f = fam(r["Kernel_Name"])
+            if f:
+                tsum[f] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+                nl[f] += 1
+        tot_t = sum(tsum.values())
+        lines.append("kernel time per frame: " + ", ".join(f"{k} {tsum[k] / F * 1e3:.3f} ms ({nl[k]} launches)" for k in ("render", "walk", "blend") if nl[k])
+                     + f" = {tot_t / F * 1e3:.3f} ms")
+        csum = collections.defaultdict(collections.Counter)
+        for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_l2"):
+            for r in rows(f"{d}/{sub}/*/*_counter_collection.csv"):
+                f = fam(r["Kernel_Name"])
+                if f:
+                    csum[r["Counter_Name"]][f] += float(r["Counter_Value"])
+        tc = lambda k: sum(csum[k].values())
+        if "FETCH_SIZE" in csum and "WRITE_SIZE" in csum:
+            hb = tc("FETCH_SIZE") * 2048 + tc("WRITE_SIZE") * 1024
+            lines.append(f"HBM traffic per frame: read {tc('FETCH_SIZE') * 2048 / F / 1e6:.1f} MB + write {tc('WRITE_SIZE') * 1024 / F / 1e6:.1f} MB = {hb / F / 1e6:.1f} MB "
+                         f"(walk kernels: {(csum['FETCH_SIZE']['walk'] * 2048 + csum['WRITE_SIZE']['walk'] * 1024) / F / 1e6:.1f} MB) = "
+                         f"{hb / tot_t / 1e9:.0f} GB/s = {hb / tot_t / 8e12:.3f} of the 8 TB/s peak")
+        if "SQ_INSTS_VALU" in csum:
+            lines.append(f"VALU instructions per frame: {tc('SQ_INSTS_VALU') / F:.4g} (render {csum['SQ_INSTS_VALU']['render'] / F:.4g}, walk {csum['SQ_INSTS_VALU']['walk'] / F:.4g})")
+        if "SQ_THREAD_CYCLES_VALU" in csum and "SQ_ACTIVE_INST_VALU" in csum:
+            lu = lambda f: csum["SQ_THREAD_CYCLES_VALU"][f] / max(64 * csum["SQ_ACTIVE_INST_VALU"][f], 1)
+            lines.append(f"VALU lane utilisation: render kernels {lu('render'):.3f}, walk kernels {lu('walk'):.3f}, all "
+                         f"{tc('SQ_THREAD_CYCLES_VALU') / (64 * tc('SQ_ACTIVE_INST_VALU')):.3f}")
+        if "TCC_HIT_sum" in csum:
+            lines.append(f"L2 hit rate {tc('TCC_HIT_sum') / (tc('TCC_HIT_sum') + tc('TCC_MISS_sum')):.1%}")
     if args.demand_json and os.path.exists(args.demand_json):
         dj = json.load(open(args.demand_json))
         lines.append("")
