@@ -1120,8 +1120,26 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || 2 * park_bytes > free_b / 4) n_rounds = 0;
         }
     }
-    const bool rounds = n_rounds > 0 && h->have_defer && a.many_mesh == 0 && a.kernel_variant == 0 && params->debug_flag == 0 &&
-                        params->rays_per_pixel > 0;
+    bool rounds = n_rounds > 0 && h->have_defer && a.many_mesh == 0 && a.kernel_variant == 0 && params->debug_flag == 0 &&
+                  params->rays_per_pixel > 0;
+    if (rounds && h->park_capacity < park_records) {
+        // the two park queues (an automatic sequence that cannot have them falls back to the plain launch)
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        free_dev(h->park_queue[0]);
+        free_dev(h->park_queue[1]);
+        h->park_capacity = 0;
+        const hipError_t e0 = hipMalloc((void**)&h->park_queue[0], park_bytes);
+        const hipError_t e1 = e0 == hipSuccess ? hipMalloc((void**)&h->park_queue[1], park_bytes) : e0;
+        if (e1 != hipSuccess) {
+            (void)hipGetLastError();
+            free_dev(h->park_queue[0]);
+            free_dev(h->park_queue[1]);
+            if (h->sort_rounds > 0) return fail(h, RT_ERR_OUT_OF_MEMORY, "sort_rounds: no device memory for the park queues");
+            rounds = false;
+        } else {
+            h->park_capacity = park_records;
+        }
+    }
     if (h->tile_feedback && params->debug_flag == 0 && n_tiles <= h->tile_capacity && n_tiles > 0 && a.kernel_variant == 0) {
         const bool same_shape = h->history_valid && h->hist_w == params->width && h->hist_h == params->height &&
                                 h->hist_rank == rank && h->hist_world == world;
@@ -1179,15 +1197,6 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         // after round, rt_walk_kernel walks the mesh for the parked rays and a render launch resumes those pixels
         // (parking them again at their next entry); the last render launch does not park: it walks what is left
         // inline.  Everything is ordered on the stream; a launch whose queue is empty ends at once.
-        if (h->park_capacity < park_records) {
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            free_dev(h->park_queue[0]);
-            free_dev(h->park_queue[1]);
-            h->park_capacity = 0;
-            HIP_TRY(h, hipMalloc((void**)&h->park_queue[0], park_bytes));
-            HIP_TRY(h, hipMalloc((void**)&h->park_queue[1], park_bytes));
-            h->park_capacity = park_records;
-        }
         if (!h->park_counts) HIP_TRY(h, hipMalloc((void**)&h->park_counts, 72 * sizeof(uint32_t)));
         HIP_TRY(h, hipMemsetAsync(h->park_counts, 0, 72 * sizeof(uint32_t), h->stream));
         a.defer_mesh = h->defer_mesh;
