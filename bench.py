@@ -234,6 +234,25 @@ def main():
             firsts.append((time.perf_counter() - t1) * 1e3)
         tracer.set_camera(cam0)
         extras["ms_first_frame_after_camera_change"] = statistics.median(firsts)
+        # independent single frames (every frame a new accumulation, as while the camera moves) pipelined across two
+        # handles on the device: each has its own stream and image, so frame k + 1's launch takes the CUs that frame
+        # k's draining waves free (the per-frame latency stays ms_per_frame_unoverlapped)
+        second = rt.RayTracer(device=device, max_width=W, max_height=H)
+        second.load_scene(arrays)
+        pair = [tracer, second]
+        for t in pair:
+            t.render(rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=0))
+            t.synchronize()
+        two = []
+        for rep in range(3):
+            t1 = time.perf_counter()
+            for i in range(64):
+                pair[i & 1].render(rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=0))
+            for t in pair:
+                t.synchronize()
+            two.append((time.perf_counter() - t1) / 64 * 1e3)
+        second.close()
+        extras["ms_per_independent_frame_two_handles"] = statistics.median(two)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -226,3 +226,38 @@ def test_timing_survives_the_event_pool_wrap(rt, tracer, cornell):
     st = tracer.stats()
     assert st.launches == n and st.frames == n and st.paths == 64 * n
     assert st.kernel_ms > 0 and st.kernel_ms / n < 5.0
+
+
+def test_independent_frames_pipelined_across_two_handles(rt, oracle, cornell):
+    """Two handles on one device (each its own stream and image) rendering independent frames alternately, without
+    a synchronisation in between -- the recipe for a moving camera: every frame equals the
+    oracle's."""
+    W, H = 160, 90
+    hs = [rt.RayTracer(0, W, H) for _ in range(2)]
+    try:
+        for h in hs:
+            h.load_scene(cornell)
+        refs = {}
+        for f in (0, 3, 7, 12):   # (frames = 0 stores; frames >= 1 would blend with the handle's own previous image)
+            p = rt.make_params(W, H, 4, 4, skybox=1, frames=0)
+            p.frames = -f   # the seed is |frames| * 719393; frames <= 0: no blend (wgsl:154-161)
+            refs[f] = oracle.render(p, cornell)[0]
+        order = [0, 3, 7, 12]
+        for i, f in enumerate(order):      # all four launches in flight before anything is read
+            p = rt.make_params(W, H, 4, 4, skybox=1, frames=0)
+            p.frames = -f
+            hs[i & 1].render(p)
+        # the last frame of each handle is what its image holds
+        assert np.array_equal(hs[0].read_image(W, H).view(np.uint32), refs[7].view(np.uint32))
+        assert np.array_equal(hs[1].read_image(W, H).view(np.uint32), refs[12].view(np.uint32))
+        # and read in between: frame by frame, alternating
+        for i, f in enumerate(order):
+            p = rt.make_params(W, H, 4, 4, skybox=1, frames=0)
+            p.frames = -f
+            hs[i & 1].render(p)
+            hs[(i + 1) & 1].render(p)      # the other handle renders the same frame concurrently
+            assert np.array_equal(hs[i & 1].read_image(W, H).view(np.uint32), refs[f].view(np.uint32)), f
+            assert np.array_equal(hs[(i + 1) & 1].read_image(W, H).view(np.uint32), refs[f].view(np.uint32)), f
+    finally:
+        for h in hs:
+            h.close()
