@@ -284,7 +284,7 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  * primary ray and its hit, 1 = memo in LDS when it fits (default), 2 = memo in global memory;
  * "vote_eighths" (0..8, default 6) and
  * "vote_patience" (default 3) = the intersection vote of the render kernels; "tile_feedback" 0 = do not
- * reorder tiles by an earlier frame's per-tile ray counts, "tile_feedback_period" = frames an order is kept (default 8); "batch_frames" = frames per launch of rt_render_frames (1..32, default 16); "batch_tile_major" 1 (default) = a batch's work items in (tile, frame) order: a tile's frames are handed out back to back, so the lanes of a wave work on the same image region, 0 = frame by frame; "multi_rccl" = gather transport of rt_render_multi (see there); "lds_top" 0 (default) / -1 what fits at full occupancy / N = wide BVH records of the biggest mesh staged into LDS by every workgroup when the scene itself is read from global memory (its first levels, numbered breadth-first at upload); "sort_rounds" -1 (default: automatic) / 0 off / 1..64 = deferred walks on scenes with one big mesh among a few: a render launch parks a pixel in front of every entry of a ray into the big mesh, a walk kernel walks the mesh for all parked rays at once, the next render launch resumes them, for that many rounds (same image, bit for bit; automatic = by the work of the launch in units of one 1920x1080 frame at 16 samples per pixel and the size of the big mesh: 3 to 12 rounds from 8 units (from 2 units, 2 rounds, for a mesh of 400 k BVH nodes and more), none below, and only while the two park queues -- 224 bytes per pixel and frame of the batch, each -- fit a quarter of the free device memory); "primary_table" 0 = compute the memoised primary ray per pixel in the render kernel instead of once per (camera, frame size); "forest" 0 = no forest items (next
+ * reorder tiles by an earlier frame's per-tile ray counts, "tile_feedback_period" = frames an order is kept (default 8); "batch_frames" = frames per launch of rt_render_frames (1..32, default 16); "batch_tile_major" 1 (default) = a batch's work items in (tile, frame) order: a tile's frames are handed out back to back, so the lanes of a wave work on the same image region, 0 = frame by frame; "multi_rccl" = gather transport of rt_render_multi (see there); "lds_top" 0 (default) / -1 what fits at full occupancy / N = wide BVH records of the biggest mesh staged into LDS by every workgroup when the scene itself is read from global memory (its first levels, numbered breadth-first at upload); "sort_rounds" -1 (default: automatic) / 0 off / 1..64 = deferred walks on scenes with one big mesh among a few: a render launch parks a pixel in front of every entry of a ray into the big mesh, a walk kernel walks the mesh for all parked rays at once, the next render launch resumes them, for that many rounds (same image, bit for bit; automatic = by the work of the launch in units of one 1920x1080 frame at 16 samples per pixel and the size of the big mesh: 3 to 12 rounds from 8 units (from 2 units, 2 rounds, for a mesh of 400 k BVH nodes and more), none below, and only while the two park queues -- 224 bytes per pixel and frame of the batch, each -- fit a quarter of the free device memory); "defer_min_nodes" (default 1024; next upload) = the smallest BVH, in internal nodes, whose mesh may be the deferred one; "primary_table" 0 = compute the memoised primary ray per pixel in the render kernel instead of once per (camera, frame size); "forest" 0 = no forest items (next
  * upload); "flat2" 0 = meshes whose BVH is a root with two leaves are walked like any other mesh instead of as straight-line code (next upload); "stack_wide" -1 auto / 0 one-dword BVH stack entries whenever legal / 1 two-dword entries. */
 int rt_set_option(rt_handle* h, const char* name, int value);
 /* Enable/disable the optional per-ray counters (node/triangle tests). */

@@ -61,6 +61,7 @@ struct rt_handle {
     // deferred walks (RenderArgs::park): the deferred mesh found at upload, the two park queues, their counters
     bool have_defer = false;
     uint32_t defer_mesh = 0, defer_xform = 0, defer_internal = 0;  // (internal nodes of its BVH)
+    int defer_min_nodes = 1024;  // option "defer_min_nodes": smallest BVH (internal nodes) that is worth deferring (next upload; tests lower it)
     // option "sort_rounds": walk-and-resume rounds of a deferred-walk sequence; 0 = off, -1 (default) = automatic: by
     // the work of the launch in units of one 1920 x 1080 frame at 16 samples per pixel and the size of the big mesh
     // (render_impl; none below 8 units, or 2 for a mesh of 400 k internal nodes and more: a round has a fixed cost, its
@@ -689,7 +690,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                 const uint32_t mi = it.a;
                 if (root_count[mi] != 0) continue;
                 const uint32_t internal = (mi + 1 < n_meshes ? wide_base[mi + 1] : (uint32_t)wide.size()) - wide_base[mi];
-                if (internal >= 1024 && internal > best_big) { best_big = internal; best_k = k; }
+                if (internal >= (uint32_t)h->defer_min_nodes && internal > best_big) { best_big = internal; best_k = k; }
             }
             if (best_k < items.size()) {
                 Item d = items[best_k];
@@ -910,6 +911,9 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         h->cull_roots = value;
     } else if (n == "lds_scene") {
         h->force_global = value ? 0 : 1;
+    } else if (n == "defer_min_nodes") {
+        if (value < 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "defer_min_nodes must be >= 1 (takes effect at the next rt_upload_scene)");
+        h->defer_min_nodes = value;
     } else if (n == "sort_rounds") {
         if (value < -1 || value > 64) return fail(h, RT_ERR_INVALID_ARGUMENT, "sort_rounds must be -1 (automatic), 0 (off) or 1 .. 64");
         h->sort_rounds = value;

@@ -323,6 +323,41 @@ def test_random_scenes(rt, oracle, tracer, seed):
 
 
 @pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_with_deferred_walks(rt, oracle, tracer, seed):
+    """The deferred walks on seeded random scenes: with defer_min_nodes = 1 the scene's biggest BVH mesh -- a blob
+    of a few dozen triangles, glass or not, in its own rotated and scaled space or not -- is the one rt_walk_kernel
+    walks; image and counters against the oracle, single frame and batch."""
+    arrays = _random_scene(rt, 2000 + seed)
+    W, H = 96, 54
+    p = rt.make_params(W, H, 5, 3, skybox=seed % 2, frames=0)
+    ref, st = oracle.render(p, arrays)
+    acc = np.zeros((H, W, 4), np.float32)
+    for f in range(3):
+        p.frames = f
+        acc, _ = oracle.render(p, arrays, image=acc)
+    p.frames = 0
+    try:
+        tracer.set_option("defer_min_nodes", 1)
+        tracer.set_option("sort_rounds", 1 + seed % 4)
+        tracer.load_scene(arrays)
+        tracer.set_counters(True)
+        tracer.reset_timing()
+        tracer.write_image(np.zeros((H, W, 4), np.float32))
+        tracer.render(p)
+        s = tracer.stats()
+        assert same(tracer.read_image(W, H), ref), seed
+        assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests), seed
+        tracer.set_counters(False)
+        tracer.write_image(np.zeros((H, W, 4), np.float32))
+        tracer.render_frames(p, 3)
+        assert same(tracer.read_image(W, H), acc), seed
+    finally:
+        tracer.set_counters(False)
+        tracer.set_option("sort_rounds", -1)
+        tracer.set_option("defer_min_nodes", 1024)
+
+
+@pytest.mark.parametrize("seed", range(8))
 def test_random_many_mesh_scenes(rt, oracle, tracer, seed):
     """Seeded random scenes with 5-40 meshes per transform group: top-level trees of random shape (and, with
     tlas_min = 2, over every pair of eligible meshes), both kernel variants, image and traversal counters."""

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Stress version of tests/test_gpu_scenes.py::test_random_scenes: N seeded random scenes, GPU (both kernel
 variants, with and without counters, one launch per frame; and three accumulating frames as one batch of
-rt_render_frames) against the CPU oracle, bit for bit.  Every fourth scene is a many-mesh one (top-level trees).  usage: fuzz_parity.py [first] [count]"""
+rt_render_frames; and both again with the scene's biggest BVH mesh deferred to rt_walk_kernel) against the CPU oracle,
+bit for bit.  Every fourth scene is a many-mesh one (top-level trees).  usage: fuzz_parity.py [first] [count]"""
 import os
 import sys
 
@@ -51,6 +52,29 @@ for seed in range(first, first + count):
     if not np.array_equal(tr.read_image(w, h).view(np.uint32), acc.view(np.uint32)):
         bad += 1
         print(f"MISMATCH seed {seed} rt_render_frames")
+    # deferred walks: the biggest BVH mesh of the scene, however small, walked by rt_walk_kernel (few-mesh scenes)
+    if seed % 4 != 3:
+        tr.set_option("defer_min_nodes", 1)
+        tr.set_option("sort_rounds", 1 + seed % 5)
+        tr.load_scene(arrays)
+        tr.set_counters(True)
+        tr.reset_timing()
+        tr.write_image(np.zeros((h, w, 4), np.float32))
+        p.frames = 0
+        tr.render(p)
+        s = tr.stats()
+        if not (np.array_equal(tr.read_image(w, h).view(np.uint32), ref.view(np.uint32)) and
+                (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests)):
+            bad += 1
+            print(f"MISMATCH seed {seed} deferred walks (single frame, counters)")
+        tr.set_counters(False)
+        tr.write_image(np.zeros((h, w, 4), np.float32))
+        tr.render_frames(p, 3)
+        if not np.array_equal(tr.read_image(w, h).view(np.uint32), acc.view(np.uint32)):
+            bad += 1
+            print(f"MISMATCH seed {seed} deferred walks (batch)")
+        tr.set_option("sort_rounds", -1)
+        tr.set_option("defer_min_nodes", 1024)
     if (seed - first) % 50 == 49:
         print(f"... {seed - first + 1} scenes, {bad} mismatches", flush=True)
 print(f"{count} scenes, {bad} mismatches")
