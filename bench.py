@@ -17,11 +17,24 @@ single-frame launches (tests/test_gpu_frames.py).  The single-frame
 (un-overlapped) latency and the first frame after a camera change are measured
 outside the timed region and reported as extra keys.
 
+`value` is the batched figure (`value_batched` is the same number under an
+explicit name); `value_per_frame_launch` is the throughput with ONE launch per
+frame -- what a host that presents every frame gets, the reference's only mode
+(src/core/app.rs:285-340) -- measured right after the timed region.  Of the
+counted rays `config.reused_fraction` are primary segments served from the
+per-pixel memo without a traversal.
+
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The frame
 is split into 8-row strips dealt round-robin to the ranks (strong scaling: the
 frame is fixed); every batch each rank renders its strips and ONE gather over
-xGMI assembles the accumulated frame on rank 0.  value = rays of the whole
-frames, all ranks, per second of the slowest rank.
+xGMI assembles the accumulated frame on rank 0 (one gather per BATCH in the
+timed region; the same frames with one launch and one gather per FRAME are
+timed afterwards and reported as `value_per_frame_launch`).  value = rays of
+the whole frames, all ranks, per second of the slowest rank.
+
+Launch: `python bench.py --gpus N` starts its own N ranks (one child process
+per GPU through torch.distributed.run, before this process touches the GPU);
+under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
 
 Prints one JSON line on rank 0 (contract in the task statement), with
 `roofline` (compulsory HBM bytes per launch / measured launch time against the
@@ -89,9 +102,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Launched bare: start the N ranks as children (one process per GPU) and leave with their exit code.  Nothing
+        # in this process has touched the GPU yet (no torch import, no HIP call), and it never does.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.exit(subprocess.run(cmd).returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
 
     import torch
@@ -100,11 +122,17 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
-    device = local_rank % torch.cuda.device_count()   # > 1 rank per device only in the gloo rehearsal
+    n_dev = torch.cuda.device_count()
+    device = local_rank % n_dev   # > 1 rank per device only in the gloo rehearsal
     torch.cuda.set_device(device)
     dist = None
+    backend_note = None
     if world > 1:
         import torch.distributed as dist
+        if args.backend == "nccl" and n_dev < world:
+            # RCCL cannot put two ranks on one device: rehearse with host-staged gloo gathers (the render path is the same)
+            args.backend = "gloo"
+            backend_note = f"gloo rehearsal: {world} ranks on {n_dev} device(s); RCCL needs one device per rank"
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
@@ -140,15 +168,22 @@ def main():
             assembler.bind_image(frame.data_ptr(), H * W)
             assembler.set_stream(stream_ptr)
 
-    def render(f0, n):
-        """Frames f0 .. f0 + n - 1, in batches of --batch frames; N > 1: one gather + assemble per batch."""
+    def render(f0, n, batch=None):
+        """Frames f0 .. f0 + n - 1, in batches of `batch` (default --batch) frames; N > 1: one gather + assemble per
+        batch.  batch = 1: one launch (and one gather) per frame."""
+        batch = max(1, args.batch) if batch is None else batch
         p = rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=f0)
         if world == 1:
-            tracer.render_frames(p, n)
+            if batch == 1:
+                for f in range(f0, f0 + n):
+                    p.frames = f
+                    tracer.render(p)
+            else:
+                tracer.render_frames(p, n)
             return
         done = 0
         while done < n:
-            nb = min(max(1, args.batch), n - done)
+            nb = min(batch, n - done)
             p.frames = f0 + done
             tracer.render_strips_frames(p, nb, rank, world)
             if args.backend == "nccl":
@@ -194,15 +229,29 @@ def main():
     rays_local, reused_local = float(st.segments), float(st.segments_reused)
     launch_ms = st.kernel_ms / max(st.launches, 1)     # render (+ blend) launch, HIP events on the tracer's stream
     frames_per_launch = st.frames / max(st.launches, 1)
+
+    # The same K frames once more with ONE launch (N > 1: and one gather + assemble) per frame: what a host that
+    # presents every frame gets.  Outside the timed region of `value`; same barrier + synchronize bracket.
+    fence()
+    tracer.reset_timing()
+    t1 = time.perf_counter()
+    render(args.warmup + args.steps, args.steps, batch=1)
+    fence()
+    elapsed_pf = time.perf_counter() - t1
+    st_pf = tracer.stats()
+    rays_pf_local = float(st_pf.segments)
+    launch_ms_pf = st_pf.kernel_ms / max(st_pf.launches, 1)
+
     if world > 1:
-        t = torch.tensor([elapsed, rays_local, launch_ms, reused_local], dtype=torch.float64,
+        t = torch.tensor([elapsed, rays_local, launch_ms, reused_local, elapsed_pf, rays_pf_local, launch_ms_pf], dtype=torch.float64,
                          device="cuda" if args.backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, rays, launch_ms, reused = float(tmax[0]), float(t[1]), float(tmax[2]), float(t[3])
+        elapsed_pf, rays_pf, launch_ms_pf = float(tmax[4]), float(t[5]), float(tmax[6])
     else:
-        rays, reused = rays_local, reused_local
+        rays, reused, rays_pf = rays_local, reused_local, rays_pf_local
 
     extras = {}
     if world == 1 and rank == 0 and not args.no_extras:
@@ -306,6 +355,14 @@ def main():
         out = {
             "metric": "Mrays/s", "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            # the two launch modes under explicit names (value == value_batched when --batch > 1)
+            "value_batched": mrays if frames_per_launch > 1 else None,
+            "value_per_frame_launch": rays_pf / elapsed_pf / 1e6,
+            "ms_per_frame_batched": ms_per_step if frames_per_launch > 1 else None,
+            "ms_per_frame_per_launch": elapsed_pf / args.steps * 1e3,
+            "value_definition": f"value = rays of {args.steps} frames / wall time with {frames_per_launch:g} frames per launch "
+                                "(intermediate frames of a batch are not observable); value_per_frame_launch = the same frames "
+                                "with one launch" + (" and one gather" if world > 1 else "") + " per frame, timed right after",
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "CornellBox-Original.obj/.mtl of the reference through the loader + BVH builder "
                     "(committed as tests/golden/cornell_scene.npz); no random inputs: the seed is Params.frames",
@@ -315,9 +372,13 @@ def main():
                        "frames_overlapped": f"{frames_per_launch:g} frames per launch (rt_render_frames: (frame, tile) work items "
                                             "+ ordered blend kernel; bit-identical to one launch per frame)"
                                             if frames_per_launch > 1 else "no: one launch per frame",
-                       "parallelism": "1 GPU" if world == 1 else f"8-row strips round-robin over {world} GPUs + 1 RCCL gather per "
-                                                                 f"batch of {frames_per_launch:g} frames",
+                       "parallelism": "1 GPU" if world == 1 else f"8-row strips round-robin over {world} GPUs + 1 "
+                                                                 f"{'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} gather per "
+                                                                 f"batch of {frames_per_launch:g} frames (value); one gather per frame in "
+                                                                 "value_per_frame_launch",
+                       "backend": backend_note or args.backend,
                        "rays_per_frame": rays / args.steps,
+                       "reused_fraction": reused / rays if rays else None,
                        "rays_traversed_per_frame": (rays - reused) / args.steps,
                        "Mrays_traversed/s": (rays - reused) / elapsed / 1e6,
                        "Mpaths/s": W * H * SPP * args.steps / elapsed / 1e6},

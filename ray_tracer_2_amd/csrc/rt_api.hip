@@ -74,10 +74,14 @@ struct rt_handle {
     int batch_tile_major = 1;  // option "batch_tile_major": (tile, frame) instead of (frame, tile) order of a batch's work items
     int batch_frames_opt = 16;  // option "batch_frames": frames per launch of rt_render_frames (1..RT_MAX_BATCH_FRAMES)
     // rt_render_multi: what the root's stream has to finish before this handle's image may be overwritten
-    hipEvent_t multi_copied = nullptr;  // (owned by the root handle, below)
+    // (owned by THIS handle, created on the root's device -- an event is recorded on a stream of its own device --,
+    // so that destroying the root first leaves nothing dangling)
+    hipEvent_t multi_copied = nullptr;
+    int multi_copied_device = -1;
     bool multi_copy_pending = false;
+    // batch scratch: the frame layout its padding rows were zeroed for
+    uint32_t scratch_w = 0, scratch_h = 0, scratch_rank = 0, scratch_world = 0, scratch_n = 0;
     // root side of rt_render_multi
-    std::vector<hipEvent_t> multi_copied_events;
     std::vector<void*> multi_comms;       // ncclComm_t per rank
     std::vector<int> multi_comm_devices;  // the device list the communicators were made for
     std::set<int> multi_peers_enabled;
@@ -120,6 +124,7 @@ struct rt_handle {
     bool have_order = false, costs_ready = false;
     uint32_t order_age = 0;
     uint32_t persistent_blocks = 0;
+    uint32_t compute_units = 1;  // of the device (rt_create); sizes the walk kernel's grid whatever "persistent_blocks" says
     float* srgb_lut = nullptr;
     // scene
     bool have_scene = false;
@@ -344,6 +349,7 @@ int rt_create(int device_ordinal, uint32_t max_width, uint32_t max_height, rt_ha
         HIP_TRY(h, hipGetDeviceProperties(&prop, device_ordinal));
         // 4 waves per SIMD (the render kernels' register budget) = 4 workgroups of 4 waves per CU
         h->persistent_blocks = (uint32_t)prop.multiProcessorCount * BLOCKS_PER_CU;
+        h->compute_units = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 1u;
     }
     static const float lut[256] = {RT_SRGB_LUT_VALUES};
     HIP_TRY(h, hipMalloc((void**)&h->srgb_lut, sizeof(lut)));
@@ -355,6 +361,7 @@ int rt_create(int device_ordinal, uint32_t max_width, uint32_t max_height, rt_ha
 void rt_destroy(rt_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->multi_copy_pending && h->multi_copied) (void)hipEventSynchronize(h->multi_copied);  // (the root still reads h->image)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_scene(h);
     free_textures(h);
@@ -366,7 +373,7 @@ void rt_destroy(rt_handle* h) {
     free_dev(h->park_queue[1]);
     free_dev(h->park_counts);
     if (h->multi_event) (void)hipEventDestroy(h->multi_event);
-    for (hipEvent_t e : h->multi_copied_events) (void)hipEventDestroy(e);
+    if (h->multi_copied) (void)hipEventDestroy(h->multi_copied);
     if (g_rccl.lib)
         for (void* c : h->multi_comms) (void)g_rccl.CommDestroy((ncclComm_t)c);
     free_dev(h->counters);
@@ -836,6 +843,16 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
     return RT_OK;
 }
 
+// rt_render_multi (device-to-device transport): the root may still be copying this handle's previous frame out of
+// h->image.  Everything that writes, rebinds or reads the image on the handle's stream waits for that copy first.
+static int wait_pending_copy(rt_handle* h) {
+    if (h->multi_copy_pending) {
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->multi_copied, 0));
+        h->multi_copy_pending = false;
+    }
+    return RT_OK;
+}
+
 int rt_upload_textures(rt_handle* h, const rt_texture_desc* descs, uint32_t n) {
     if (!h || (n && !descs)) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
     if (n > RT_MAX_TEXTURES) return fail(h, RT_ERR_CAPACITY, "Cannot load more than 64 textures");
@@ -960,11 +977,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     if (need_texels > h->image_texels)
         return fail(h, RT_ERR_CAPACITY, "image larger than the bound image buffer");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->multi_copy_pending) {
-        // rt_render_multi: the root may still be copying this handle's previous frame
-        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->multi_copied, 0));
-        h->multi_copy_pending = false;
-    }
+    if (int rc = wait_pending_copy(h); rc != RT_OK) return rc;
     RenderArgs a{};
     a.params = *params;
     a.camera = h->camera;
@@ -977,8 +990,15 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             h->batch_scratch_texels = 0;
             HIP_TRY(h, hipMalloc((void**)&h->batch_scratch, scratch_stride * n_batch * sizeof(float4)));
             h->batch_scratch_texels = scratch_stride * n_batch;
-            // (the padding rows of a ragged last strip are never rendered: they blend as zeros)
+            h->scratch_w = 0;  // (new memory: zero it below)
+        }
+        // The padding rows of a ragged last strip are never rendered: they must blend as zeros, not as the samples an
+        // earlier batch of another shape left there.  Zero the scratch whenever the layout of the batch changes.
+        if (h->scratch_w != params->width || h->scratch_h != params->height || h->scratch_rank != rank ||
+            h->scratch_world != world || h->scratch_n != n_batch) {
             HIP_TRY(h, hipMemsetAsync(h->batch_scratch, 0, scratch_stride * n_batch * sizeof(float4), h->stream));
+            h->scratch_w = params->width; h->scratch_h = params->height; h->scratch_rank = rank;
+            h->scratch_world = world; h->scratch_n = n_batch;
         }
         a.batch_frames = n_batch;
         a.batch_stride = scratch_stride;
@@ -1229,7 +1249,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             {
                 RenderArgs w = a;
                 w.top_count = 0;  // (nothing is staged into the walk kernel's LDS)
-                HIP_TRY(h, launch_walk(w, h->persistent_blocks / BLOCKS_PER_CU, h->stream));
+                HIP_TRY(h, launch_walk(w, h->compute_units, h->stream));
             }
             HIP_TRY(h, fresh_counter());
             a.park = last ? 0u : 1u;
@@ -1310,6 +1330,7 @@ int rt_assemble_strips(rt_handle* h, const void* gathered_device, uint32_t width
     if ((uint64_t)width * height > h->image_texels)
         return fail(h, RT_ERR_CAPACITY, "image larger than the bound image buffer");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = wait_pending_copy(h); rc != RT_OK) return rc;
     unsigned long long pad = rt_strip_texels(width, height, 0, world);
     HIP_TRY(h, launch_assemble((const float4*)gathered_device, h->image, width, height, world, pad, h->stream));
     return RT_OK;
@@ -1336,7 +1357,10 @@ static int render_multi_impl(rt_handle** per_gpu, int n_gpus, const rt_params* p
     for (int r = 0; r < n_gpus; ++r)
         for (int q = 0; q < r; ++q)
             if (per_gpu[r]->device == per_gpu[q]->device) distinct = false;
-    const bool use_rccl = distinct && ((root->multi_rccl == 1 && n_gpus > 1) || root->multi_rccl == 2);
+    bool use_rccl = distinct && ((root->multi_rccl == 1 && n_gpus > 1) || root->multi_rccl == 2);
+    if (root->multi_rccl == 2 && !distinct)
+        return fail(root, RT_ERR_INVALID_ARGUMENT, "multi_rccl = 2 (RCCL always) needs one device per handle: a communicator cannot "
+                                                   "hold two ranks of one device (multi_rccl = 1 uses device-to-device copies there)");
     // root-side staging, grown on demand
     HIP_TRY(root, hipSetDevice(root->device));
     if (root->multi_gathered_texels < pad * world) {
@@ -1351,23 +1375,47 @@ static int render_multi_impl(rt_handle** per_gpu, int n_gpus, const rt_params* p
         HIP_TRY(root, hipMalloc((void**)&root->multi_frame, frame_texels * sizeof(float4)));
         root->multi_frame_texels = frame_texels;
     }
-    while (root->multi_copied_events.size() < (size_t)n_gpus) {  // events of the root's device, one per rank
-        hipEvent_t e = nullptr;
-        HIP_TRY(root, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        root->multi_copied_events.push_back(e);
+    for (int r = 0; r < n_gpus; ++r) {  // every rank's "the root has copied my strips" event: of the root's device
+        rt_handle* h = per_gpu[r];
+        if (h->multi_copied && h->multi_copied_device == root->device) continue;
+        if (h->multi_copied) {
+            if (h->multi_copy_pending) (void)hipEventSynchronize(h->multi_copied);
+            h->multi_copy_pending = false;
+            (void)hipEventDestroy(h->multi_copied);
+            h->multi_copied = nullptr;
+        }
+        HIP_TRY(root, hipEventCreateWithFlags(&h->multi_copied, hipEventDisableTiming));
+        h->multi_copied_device = root->device;
     }
     if (use_rccl) {
         std::vector<int> devs(n_gpus);
         for (int r = 0; r < n_gpus; ++r) devs[r] = per_gpu[r]->device;
         if (root->multi_comm_devices != devs) {
-            if (!g_rccl.load()) return fail(root, RT_ERR_DEVICE, g_rccl.why + " (option multi_rccl = 0 selects device-to-device copies)");
-            multi_drop_comms(root);
-            std::vector<ncclComm_t> comms(n_gpus);
-            NCCL_TRY(root, g_rccl.CommInitAll(comms.data(), n_gpus, devs.data()));
-            for (ncclComm_t c : comms) root->multi_comms.push_back((void*)c);
-            root->multi_comm_devices = devs;
+            // Automatic mode (multi_rccl = 1) falls back to device-to-device copies when librccl cannot be loaded or
+            // the communicators cannot be made (the reason stays in rt_last_error); multi_rccl = 2 insists.
+            std::string why;
+            if (!g_rccl.load()) {
+                why = g_rccl.why;
+            } else {
+                multi_drop_comms(root);
+                std::vector<ncclComm_t> comms(n_gpus);
+                const ncclResult_t r = g_rccl.CommInitAll(comms.data(), n_gpus, devs.data());
+                if (r != ncclSuccess) {
+                    why = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r);
+                } else {
+                    for (ncclComm_t c : comms) root->multi_comms.push_back((void*)c);
+                    root->multi_comm_devices = devs;
+                }
+            }
+            if (!why.empty()) {
+                if (root->multi_rccl == 2) return fail(root, RT_ERR_DEVICE, why + " (option multi_rccl = 0 selects device-to-device copies)");
+                root->err = "rt_render_multi: " + why + "; gathering with device-to-device copies instead";
+                root->multi_rccl = 0;  // (do not try again on every frame)
+                use_rccl = false;
+            }
         }
-    } else {
+    }
+    if (!use_rccl) {
         // peer access for the device-to-device copies (without it the runtime stages them through the host)
         for (int r = 1; r < n_gpus; ++r) {
             const int peer = per_gpu[r]->device;
@@ -1428,8 +1476,7 @@ static int render_multi_impl(rt_handle** per_gpu, int n_gpus, const rt_params* p
                                                  n * sizeof(float4), root->stream));
             if (h->stream != root->stream) {
                 // the rank's next render overwrites h->image: it has to wait for this copy
-                HIP_TRY(root, hipEventRecord(root->multi_copied_events[r], root->stream));
-                h->multi_copied = root->multi_copied_events[r];
+                HIP_TRY(root, hipEventRecord(h->multi_copied, root->stream));
                 h->multi_copy_pending = true;
             }
         }
@@ -1476,6 +1523,7 @@ int rt_read_image(rt_handle* h, float* out, size_t bytes) {
     if (bytes > h->image_texels * sizeof(float4))
         return fail(h, RT_ERR_INVALID_ARGUMENT, "read larger than the image");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = wait_pending_copy(h); rc != RT_OK) return rc;
     HIP_TRY(h, hipMemcpyAsync(out, h->image, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return RT_OK;
@@ -1486,6 +1534,7 @@ int rt_write_image(rt_handle* h, const float* in, size_t bytes) {
     if (bytes > h->image_texels * sizeof(float4))
         return fail(h, RT_ERR_INVALID_ARGUMENT, "write larger than the image");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = wait_pending_copy(h); rc != RT_OK) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->image, in, bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return RT_OK;
@@ -1531,6 +1580,7 @@ int rt_reset_timing(rt_handle* h) {
 int rt_set_stream(rt_handle* h, void* hip_stream) {
     if (!h) return RT_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = wait_pending_copy(h); rc != RT_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (size_t i = 0; i < h->ev_used; ++i) {  // (the old stream is idle: its recorded times are final)
         float ms = 0.0f;
@@ -1545,6 +1595,7 @@ int rt_set_stream(rt_handle* h, void* hip_stream) {
 int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels) {
     if (!h) return RT_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = wait_pending_copy(h); rc != RT_OK) return rc;  // (the caller may free the old buffer after this call)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (device_ptr) {
         h->image = (float4*)device_ptr;

@@ -1529,12 +1529,13 @@ DEV void park_load_hit(const RenderArgs& a, uint32_t slot, Isect& I, CompactHit&
 
 template <bool LDS, bool STATS, bool TLAS, bool PARK = false>
 DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
-                       uint32_t& n_reused_wave, int& node_tests, int& tri_tests, uint32_t resume_slot = 0xffffffffu) {
+                       bool& reused, int& node_tests, int& tri_tests, uint32_t resume_slot = 0xffffffffu) {
     // (a resumed pixel was parked behind path_begin: its segment has begun)
     const uint32_t mode = PARK && resume_slot != 0xffffffffu ? (uint32_t)STEP_RESUME : path_begin<STATS>(a, s, ls, starve);
-    // segments served from the memo, counted per wave (a scalar add): Mrays/s can then be stated for
-    // traversed rays as well
-    n_reused_wave += (uint32_t)__popcll(__ballot(mode == STEP_REUSE));
+    // segments served from the memo: the caller counts them per wave, OUTSIDE its `if (active)` (a ballot + a scalar
+    // add with every lane of the wave present -- counted in here, under the divergent branch, the sum lived in the
+    // active lanes only and was lost for every iteration lane 0 sat out)
+    reused = mode == STEP_REUSE;
     if (mode == STEP_WAIT) return PATH_CONTINUE;
     Hit hit;
     hit.hit = false;
@@ -1705,6 +1706,7 @@ template <bool STATS>
 DEV void flush_counters(const RenderArgs& a, uint32_t n_segments, uint32_t n_reused_wave, int node_tests, int tri_tests) {
     if (a.counters && __ballot(n_segments != 0u || (STATS && (node_tests | tri_tests) != 0)) != 0ull) {
         atomicAdd(&a.counters->segments, (unsigned long long)n_segments);
+        // (n_reused_wave is the same in every lane: accumulated from ballots taken with the whole wave present)
         if (n_reused_wave != 0u && (threadIdx.x & 63u) == 0u) atomicAdd(&a.counters->reused, (unsigned long long)n_reused_wave);
         if (STATS) {
             atomicAdd(&a.counters->node_tests, (unsigned long long)node_tests);
@@ -1733,9 +1735,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     bool active = valid && a.params.rays_per_pixel > 0;
     uint32_t n_segments = 0, n_reused_wave = 0;
     int node_tests = 0, tri_tests = 0;
-    while (active) {
-        if (path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, n_reused_wave, node_tests, tri_tests) == PATH_PIXEL_DONE)
+    while (__ballot(active) != 0ull) {
+        bool reused = false;
+        if (active && path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, reused, node_tests, tri_tests) == PATH_PIXEL_DONE)
             active = false;
+        n_reused_wave += (uint32_t)__popcll(__ballot(reused));  // (wave-uniform: every lane is here)
     }
     if (valid) pixel_finish<total_in_lds(LDS)>(a, s, ls);
     if (a.tile_cost && tile_ok) {  // one store per wave: the tile's rays
@@ -1864,8 +1868,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         }
         TIC(t15);
         uint32_t step = PATH_CONTINUE;
+        bool reused = false;
         if (active) {
-            step = path_step<LDS, STATS, TLAS, PARK>(a, s, ls, starve, n_segments, n_reused_wave, node_tests, tri_tests, resume_slot);
+            step = path_step<LDS, STATS, TLAS, PARK>(a, s, ls, starve, n_segments, reused, node_tests, tri_tests, resume_slot);
             resume_slot = 0xffffffffu;
             if (step == PATH_PIXEL_DONE) {
                 DIAG(16);
@@ -1875,6 +1880,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
             }
         }
         if (step == PATH_PARK) active = false;  // (parked by path_step)
+        n_reused_wave += (uint32_t)__popcll(__ballot(reused));  // (wave-uniform: every lane is here)
         TOC(t15, 15);
     }
     flush_counters<STATS>(a, n_segments, n_reused_wave, node_tests, tri_tests);

@@ -72,7 +72,32 @@ def main():
     out["transcript_rgba"] = np.stack(vals)
     np.savez_compressed(os.path.join(HERE, "cornell_golden.npz"), **out)
     print("wrote", len(out), "arrays")
+    library_scenes()
+
+
+def library_scenes():
+    """(7) The two library scenes that run on the reference's own data files and nothing else: `texture_test`
+    (scene.rs:280-309: a unit sphere textured with assets/earthmap.png -- the real PNG -> horizontal flip -> sRGB ->
+    spherical-uv path of asset.rs:60-80 and wgsl:248-252,454-455) and `obj_test` (scene.rs:310-364: dragon.obj
+    without its .mtl, an emissive quad, three spheres).  Scene arrays (with the decoded, flipped texture) + small
+    oracle images: the path-traced frame after two accumulated frames and the debug views 1 (normal) and 3 (uv)."""
+    out = {}
+    for name in ("texture_test", "obj_test"):
+        arr = rt.SceneArrays.from_scene(rt.Scene.from_name(name, ASSETS))
+        arr.save(os.path.join(HERE, f"{name}_scene.npz"))
+        img = np.zeros((54, 96, 4), np.float32)
+        for f in range(2):
+            img, st = oracle.render(rt.make_params(96, 54, 3, 4, skybox=1, frames=f), arr, image=img)
+        out[f"{name}_frame"] = img
+        out[f"{name}_segments_frame1"] = np.array([st.segments], np.uint64)
+        for dbg in (1, 2, 3):
+            out[f"{name}_debug_{dbg}"], _ = oracle.render(rt.make_params(96, 54, 3, 1, debug_flag=dbg, debug_scale=4), arr)
+    np.savez_compressed(os.path.join(HERE, "library_scenes_golden.npz"), **out)
+    print("wrote the texture_test / obj_test fixtures")
 
 
 if __name__ == "__main__":
-    main()
+    if "--library-scenes" in sys.argv:   # only (7): leaves the Cornell fixtures alone
+        library_scenes()
+    else:
+        main()

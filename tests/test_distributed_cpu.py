@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2/3 `gloo` processes split the frame into
+"""N > 1 path on CPU: world_size-2/3/8 `gloo` processes split the frame into
 8-row strips, render their strips (with the CPU oracle standing in for the HIP
 library), do ONE gather, and rank 0's assembled frame must be bit-identical to
 the single-process frame -- the multi-GPU parity property of SURVEY.md 8e."""
@@ -56,7 +56,9 @@ def _worker(rank, world, port, width, height, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape", [(2, (64, 40)), (3, (48, 72))])
+# (8, 16 x 1080): the strip counts of the 8-GPU node at 1080 rows -- 135 strips dealt 17 x 7 + 16, so the last rank's
+# buffer is one strip shorter than the padded gather slot
+@pytest.mark.parametrize("world,shape", [(2, (64, 40)), (3, (48, 72)), (8, (16, 1080))])
 def test_strip_split_gather_is_bit_identical(rt, oracle, cornell, tmp_path, world, shape):
     import torch.multiprocessing as mp
     width, height = shape

@@ -77,6 +77,33 @@ def test_render_frames_with_the_stats_counters(rt, oracle, tracer, cornell):
     assert s.segments_reused == 0   # the counter kernels re-intersect memoised rays so that the counters stay the shader's
 
 
+@pytest.mark.parametrize("variant,lds,batch", [(0, 1, 0), (1, 1, 0), (0, 0, 0), (1, 0, 0), (0, 1, 6), (0, 0, 6)])
+def test_segments_reused_is_exact(rt, tracer, cornell, variant, lds, batch):
+    """rt_stats.segments_reused (segments served from the primary-ray memo): with the zero-strength Cornell camera every
+    pixel's primary ray is constant (no -0 involved at an even width), so every sample but a pixel's first takes its
+    primary hit from the memo: exactly W * H * (spp - 1) per frame, whichever kernel renders the frame and however
+    many lanes of a wave sit out an iteration."""
+    w, h, spp, frames = 200, 104, 5, 6
+    tracer.load_scene(cornell)
+    tracer.set_option("kernel_variant", variant)
+    tracer.set_option("lds_scene", lds)
+    try:
+        tracer.reset_timing()
+        if batch:
+            tracer.set_option("batch_frames", batch)
+            tracer.render_frames(rt.make_params(w, h, 4, spp, skybox=1, frames=0), frames)
+        else:
+            for f in range(frames):
+                tracer.render(rt.make_params(w, h, 4, spp, skybox=1, frames=f))
+        s = tracer.stats()
+    finally:
+        tracer.set_option("kernel_variant", -1)
+        tracer.set_option("lds_scene", 1)
+        tracer.set_option("batch_frames", 16)
+    assert s.segments_reused == w * h * (spp - 1) * frames
+    assert s.paths == w * h * spp * frames and s.segments - s.segments_reused >= w * h * frames
+
+
 @pytest.mark.parametrize("kw", [dict(lds_scene=0), dict(pixel_cache=0), dict(pixel_cache=2), dict(tile_feedback=0), dict(batch_tile_major=0)])
 def test_render_frames_under_every_kernel_option(rt, tracer, cornell, kw):
     w, h = 160, 90
@@ -188,6 +215,50 @@ def test_render_multi_gather_through_rccl(rt, tracer, cornell):
         assert np.array_equal(bits(got), bits(want))
     finally:
         t.close()
+
+
+def test_render_multi_eight_handles_at_the_node_shape(rt, tracer, cornell):
+    """rt_render_multi(_frames) with the 8 ranks of one node, all on this one device: a 1080-row frame is 135 strips
+    dealt 17 x 7 + 16 (rank 7's buffer is a strip shorter than its padded gather slot).  Everything of the multi-GPU
+    path runs here except the transfer between two devices itself (device-to-device copies on one device; the RCCL
+    transport is covered with a one-rank communicator above and refuses handles that share a device): strip renders on
+    eight streams, the root's copy events that the ranks' next renders wait for, gather layout, assemble -- frame by
+    frame without read-back, in overlapped batches, with a rank's image read and written in between, and with the
+    root destroyed first."""
+    w, h, spp, nb = 72, 1080, 2, 3
+    tracer.load_scene(cornell)
+    want = sequential(rt, tracer, w, h, nb, spp, 0, 6)
+    ranks = [rt.RayTracer(0, w, h) for _ in range(8)]
+    try:
+        for t in ranks:
+            t.load_scene(cornell)
+        assert [t.strip_texels(w, h, r, 8) // (8 * w) for r, t in enumerate(ranks)] == [17] * 7 + [16]
+        for f in range(6):
+            rt.render_multi(ranks, rt.make_params(w, h, nb, spp, skybox=1, frames=f), read_back=False)
+        assert np.array_equal(bits(rt.read_multi_frame(ranks[0], w, h)), bits(want))
+        # a rank's image rewritten right behind a non-blocking call (the root may still be copying it), then batches
+        for t in ranks:
+            t.write_image(np.zeros((h, w, 4), np.float32))
+        rt.render_multi(ranks, rt.make_params(w, h, nb, spp, skybox=1, frames=0), read_back=False, n_frames=3)
+        part = ranks[7].read_texels(ranks[7].strip_texels(w, h, 7, 8))      # rank 7's compact strips after 3 frames
+        got = rt.render_multi(ranks, rt.make_params(w, h, nb, spp, skybox=1, frames=3), read_back=True, n_frames=3)
+        assert np.array_equal(bits(got), bits(want))
+        three = sequential(rt, tracer, w, h, nb, spp, 0, 3)
+        from ray_tracer_2_amd import parallel
+        assert np.array_equal(bits(part.reshape(-1, w, 4)), bits(three[parallel.local_rows(h, 7, 8)]))
+        # RCCL cannot hold two ranks of one device: insisting on it is an error, not a silent switch of transport
+        ranks[0].set_option("multi_rccl", 2)
+        with pytest.raises(rt.RtError):
+            rt.render_multi(ranks, rt.make_params(w, h, nb, spp, skybox=1, frames=0), read_back=False)
+        ranks[0].set_option("multi_rccl", 1)
+        # the root goes first, with copies of the others' strips possibly still in flight
+        rt.render_multi(ranks, rt.make_params(w, h, nb, spp, skybox=1, frames=6), read_back=False)
+        ranks[0].close()
+        ranks[1].render(rt.make_params(w, h, nb, spp, skybox=1, frames=0))
+        ranks[1].synchronize()
+    finally:
+        for t in ranks:
+            t.close()
 
 
 @pytest.mark.skipif("__import__('torch').cuda.device_count() < 2")
