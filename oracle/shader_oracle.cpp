@@ -70,7 +70,9 @@ static inline vec3 cross(vec3 a, vec3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 static inline float length(vec3 a) { return rtm::sqrt_(dot(a, a)); }
-static inline vec3 normalize(vec3 a) { return a / length(a); }
+// normalize(): precision is implementation-defined in WGSL; this build's canonical form is v * (1 / length(v)) with a
+// correctly rounded reciprocal ("Canonical arithmetic")
+static inline vec3 normalize(vec3 a) { return a * (1.0f / length(a)); }
 static inline float distance(vec3 a, vec3 b) { return length(a - b); }
 static inline vec3 reflect(vec3 I, vec3 N) { return I - (2.0f * dot(N, I)) * N; }
 static inline vec3 refract(vec3 I, vec3 N, float eta) {

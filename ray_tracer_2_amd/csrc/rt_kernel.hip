@@ -92,7 +92,6 @@ DEV f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
 DEV f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 DEV f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 DEV f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
-DEV f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
 DEV f4 operator+(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 DEV f4 operator*(f4 a, f4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
 DEV f4 operator*(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
@@ -108,7 +107,11 @@ DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 DEV f3 cross3(f3 a, f3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-DEV f3 normalize3(f3 a) { return a / rtm::sqrt_(dot3(a, a)); }
+// WGSL leaves normalize()'s precision to the implementation ("inherited from e / length(e)", with 2.5 ULP for a
+// division); drivers multiply by an inverse square root.  Canonical here (round 3): ONE correctly rounded reciprocal
+// of the correctly rounded length, then three multiplications -- 19 instructions fewer than three IEEE divisions,
+// five or so times per segment.  The oracle's normalize() is the same two-step form.
+DEV f3 normalize3(f3 a) { return a * (1.0f / rtm::sqrt_(dot3(a, a))); }
 DEV f3 mix3(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }
 DEV f4 mix4(f4 a, f4 b, float t) { return a * (1.0f - t) + b * t; }
 DEV f3 reflect3(f3 I, f3 N) { return I - (2.0f * dot3(N, I)) * N; }

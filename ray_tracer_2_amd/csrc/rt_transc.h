@@ -14,9 +14,10 @@
 // libm (<= 2 ULP on the ranges the shader uses).
 //
 // Algorithms: argument reduction + polynomial kernels in the style of the
-// classic float libm routines (log: msun e_logf; sin/cos: msun k_sinf/k_cosf
-// with a 3-term Cody-Waite reduction; exp2/exp: own minimax polynomials;
-// atan/asin: Cephes atanf/asinf).  msun notice: "Developed at SunPro, a Sun
+// classic float libm routines (log2: msun e_logf's kernel; log, sin/cos: own
+// near-minimax polynomials (tools/micro/fit_transc.py) behind msun's argument
+// reductions -- a 3-term Cody-Waite reduction for the angles; exp2/exp: own
+// minimax polynomials; atan/asin: Cephes atanf/asinf).  msun notice: "Developed at SunPro, a Sun
 // Microsystems, Inc. business. Permission to use, copy, modify, and
 // distribute this software is freely granted, provided that this notice is
 // preserved."
@@ -105,6 +106,11 @@ RT_HD float log1p_kernel(float f, float* hfsq_out) {
     return s * (hfsq + R);
 }
 
+// log(x) = k ln2 + log(1 + f), log(1 + f) = f - f^2/2 + f^3 P(f) with P of degree 7 (near-minimax for the relative
+// error on [sqrt(1/2) - 1, sqrt(2) - 1], fit error 0.1 ULP: tools/micro/fit_transc.py), Horner with explicit fma.
+// Round 3: replaces the msun form above (a correctly rounded division plus 11 unfused operations) -- Box-Muller
+// (wgsl:181-185) takes a logarithm per normal deviate, three per bounce.  <= 1 ULP on rand()'s outputs
+// (tests/test_transc.py).  log2_ / pow_ keep the split-precision msun kernel.
 RT_HD float log_(float x) {
     uint32_t ux = f2u(x);
     if ((ux & 0x7fffffffu) == 0) return u2f(0xff800000u);  // log(+-0) = -inf
@@ -114,12 +120,23 @@ RT_HD float log_(float x) {
             return x + x;                   // NaN
         return u2f(0x7fc00000u);            // negative -> NaN
     }
-    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;  // (ln2_hi has 9 trailing zero bits: k * ln2_hi is exact)
+    const float P0 = 0.3333333134651184f, P1 = -0.250008225440979f, P2 = 0.20001231133937836f,
+                P3 = -0.16623249650001526f, P4 = 0.14201568067073822f, P5 = -0.13161104917526245f,
+                P6 = 0.12763474881649017f, P7 = -0.07634374499320984f;
     LogRed r = log_reduce(x);
-    float hfsq;
-    float sr = log1p_kernel(r.f, &hfsq);
-    float dk = (float)r.k;
-    return (((sr + dk * ln2_lo) - hfsq) + r.f) + dk * ln2_hi;
+    const float f = r.f, z = f * f, dk = (float)r.k;
+    float p = fma_(P7, f, P6);
+    p = fma_(p, f, P5);
+    p = fma_(p, f, P4);
+    p = fma_(p, f, P3);
+    p = fma_(p, f, P2);
+    p = fma_(p, f, P1);
+    p = fma_(p, f, P0);
+    float y = (f * z) * p;
+    y = fma_(dk, ln2_lo, y);
+    y = fma_(-0.5f, z, y);
+    return fma_(dk, ln2_hi, y + f);
 }
 
 RT_HD float log2_(float x) {
@@ -195,30 +212,6 @@ RT_HD float exp_(float x) {
 RT_HD float pow_(float x, float y) { return exp2_(y * log2_(x)); }
 
 // ------------------------------------------------------------ sin/cos ----
-RT_HD float sin_kernel(float x) {
-    const float S1 = -1.6666667163e-01f, S2 = 8.3333337680e-03f, S3 = -1.9841270114e-04f,
-                S4 = 2.7557314297e-06f, S5 = -2.5050759689e-08f, S6 = 1.5896910177e-10f;
-    float z = x * x;
-    float v = z * x;
-    float r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    return x + v * (S1 + z * r);
-}
-
-RT_HD float cos_kernel(float x) {
-    const float C1 = 4.1666667908e-02f, C2 = -1.3888889225e-03f, C3 = 2.4801587642e-05f,
-                C4 = -2.7557314297e-07f, C5 = 2.0875723372e-09f, C6 = -1.1359647598e-11f;
-    float z = x * x;
-    float r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
-    uint32_t ix = f2u(x) & 0x7fffffffu;
-    // |x| < 0.3: 1 - (z/2 - z r); above: the same with qx ~ |x|/4 moved from one term to the other.  One
-    // expression for both (qx = 0 gives the first form bit for bit: z/2 - 0 and 1 - 0 are exact), so that a wave
-    // whose lanes fall on both sides does not execute two paths.
-    float qx = (ix < 0x3e99999au) ? 0.0f : ((ix > 0x3f480000u) ? 0.28125f : u2f(ix - 0x01000000u));  // ~|x|/4
-    float hz = 0.5f * z - qx;
-    float a = 1.0f - qx;
-    return a - (hz - z * r);
-}
-
 // x = n*(pi/2) + r, |r| <= ~pi/4.  Three-term Cody-Waite with fma; accurate
 // for |x| < ~1e5 (the shader only passes angles in [0, 2*pi]).  Callers keep |x| < 2^31 so that the
 // float -> int conversion of n is defined (it saturates on gfx950 and yields INT_MIN on x86: found by
@@ -244,29 +237,43 @@ RT_HD TrigRed trig_reduce(float x) {
     return t;
 }
 
+// sin(r) or cos(r) on the reduced interval as ONE polynomial with per-lane coefficients (round 3; the msun pair
+// above evaluated both kernels and selected, 55 instructions on gfx950 -- Box-Muller takes a cosine per deviate):
+//   sin(r) = r + (r z)(S1 + S2 z + S3 z^2 + S4 z^3),   cos(r) = 1 + z (C0 + C1 z + C2 z^2 + C3 z^3),   z = r^2
+// -- the same shape b + a * p(z) with (a, b) = (r z, r) or (z, 1).  Near-minimax coefficients (fit error < 0.001 ULP:
+// tools/micro/fit_transc.py), Horner with explicit fma.  Properties trig_signbits relies on: the cosine form is
+// positive on the reduced interval; the sine form has the sign of r, and is +0 for r = +-0.
+RT_HD float trig_poly(float r, bool sine) {
+    const float S1 = -0.1666666716337204f, S2 = 0.008333329111337662f, S3 = -0.00019839330343529582f,
+                S4 = 2.7182745725440327e-06f;
+    const float C0 = -0.5f, C1 = 0.04166662320494652f, C2 = -0.0013886759988963604f, C3 = 2.4390043108724058e-05f;
+    const float z = r * r;
+    float p = fma_(z, sine ? S4 : C3, sine ? S3 : C2);
+    p = fma_(z, p, sine ? S2 : C1);
+    p = fma_(z, p, sine ? S1 : C0);
+    return fma_(sine ? r * z : z, p, sine ? r : 1.0f);
+}
+
 RT_HD float sin_(float x) {
     uint32_t ax = f2u(x) & 0x7fffffffu;
     if (ax >= 0x4f000000u) return u2f(0x7fc00000u);  // |x| >= 2^31, inf, NaN -> NaN
-    // (no shortcut for |x| < pi/4: there n = +-0, r = fma(-+0, P1, x) = x and q = 0, so the general path returns
-    // sin_kernel(x) itself -- checked over every float below pi/4 -- and a wave whose lanes straddle pi/4 would
-    // execute both paths)
+    // (no shortcut for |x| < pi/4: there n = +-0, r = fma(-+0, P1, x) = x and q = 0, so the general path evaluates
+    // the sine form at x itself, and a wave whose lanes straddle pi/4 does not execute two paths)
     TrigRed t = trig_reduce(x);
-    float s = sin_kernel(t.r), c = cos_kernel(t.r);
-    float v = (t.q & 1) ? c : s;
+    float v = trig_poly(t.r, (t.q & 1) == 0);
     return (t.q & 2) ? -v : v;
 }
 
 RT_HD float cos_(float x) {
     uint32_t ax = f2u(x) & 0x7fffffffu;
     if (ax >= 0x4f000000u) return u2f(0x7fc00000u);
-    TrigRed t = trig_reduce(x);  // (|x| < pi/4: n = 0, r = x, the result is cos_kernel(x); see sin_)
-    float s = sin_kernel(t.r), c = cos_kernel(t.r);
-    float v = (t.q & 1) ? s : c;
+    TrigRed t = trig_reduce(x);  // (|x| < pi/4: n = 0, r = x, the result is the cosine form at x; see sin_)
+    float v = trig_poly(t.r, (t.q & 1) != 0);
     return ((t.q + 1) & 2) ? -v : v;
 }
 
 // Sign bits of cos_(x) and sin_(x) for finite x, without evaluating the
-// polynomials: cos_kernel is positive on the reduced interval and sin_kernel(r)
+// polynomials: trig_poly's cosine form is positive on the reduced interval and its sine form
 // has the sign of r (and is +0 for r = +-0), so the signs follow from the
 // quadrant and from r alone.  Used where only the sign of a product with an
 // exact zero survives (rt_kernel.hip, zero-strength camera jitter).
