@@ -142,6 +142,8 @@ struct rt_handle {
     bool stack_wide = false, stack_must_wide = false;
     int force_stack_wide = -1;  // option "stack_wide": -1 auto, 0 one-dword entries when legal, 1 two-dword entries
     bool has_forest = false;
+    bool plain_materials = false;  // no spheres, no glass, no textured material (rt_upload_scene)
+    int specialise = 1;            // option "specialise": 0 = always the general kernels
     int pixel_cache_opt = 1;  // option "pixel_cache"
     int vote_eighths = 6, vote_patience = 3;  // options "vote_eighths", "vote_patience"
     int use_tlas = 1;  // option "tlas": 0 = every mesh is a single item (takes effect at the next upload)
@@ -822,6 +824,14 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->tlas_entries = tlas_entries;
         h->has_tlas = has_tlas;
         h->has_forest = !forest_entries.empty();
+        {
+            bool plain = n_spheres == 0;
+            for (uint32_t i = 0; i < n_meshes && plain; ++i) {
+                const rt_material& m = meshes[i].material;
+                if (m.flag == RT_MATERIAL_GLASS || (m.flag == RT_MATERIAL_TEXTURE && m.diffuse_index != -1)) plain = false;
+            }
+            h->plain_materials = plain;
+        }
         h->n_items = (uint32_t)items.size();
         h->top_base = top_mesh_base;
         h->top_available = top_mesh_records >= 64 ? std::min<uint32_t>(top_mesh_records, 2048u) : 0u;
@@ -940,6 +950,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "multi_rccl") {
         if (value < 0 || value > 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "multi_rccl must be 0 (peer copies), 1 (RCCL between distinct devices) or 2 (RCCL always)");
         h->multi_rccl = value;
+    } else if (n == "specialise") {
+        h->specialise = value ? 1 : 0;
     } else if (n == "batch_tile_major") {
         h->batch_tile_major = value ? 1 : 0;
     } else if (n == "batch_frames") {
@@ -1026,6 +1038,12 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.cull_roots = (h->roots_are_unions && (h->cull_roots == 1 || (h->cull_roots < 0 && h->n_meshes >= 16))) ? 1u : 0u;
     a.many_mesh = (h->has_tlas || (a.cull_roots && !h->has_forest)) ? 1u : 0u;
     a.forest_cull = h->cull_roots != 0 ? 1u : 0u;
+    {
+        uint32_t ds, dv;
+        memcpy(&ds, &h->camera.defocus_strength, 4);
+        memcpy(&dv, &h->camera.diverge_strength, 4);
+        a.simple = (h->specialise && h->plain_materials && ds == 0u && dv == 0u) ? 1u : 0u;  // (both strengths +0)
+    }
     // the per-lane primary-ray cache is used when it still leaves room for 4 workgroups per CU
     a.textures = h->textures;
     a.srgb_lut = h->srgb_lut;

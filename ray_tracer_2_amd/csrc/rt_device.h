@@ -160,6 +160,8 @@ struct RenderArgs {
     uint32_t stack_wide;     // 1 => two dwords per entry (a leaf reference does not fit one dword)
     uint32_t tlas_entries;   // per-lane TLAS stack depth (1 dword per entry), >= 1
     uint32_t many_mesh;      // 1 => use the kernels with top-level trees / root-box culling compiled in
+    uint32_t simple;         // 1 => no spheres, no glass, no textured material, camera without jitter: the few-mesh product
+                             // kernels have an instantiation with those branches compiled out (option "specialise")
     uint32_t pixel_cache;    // per-lane primary-ray memo (PIXEL_MEMO_DWORDS per lane): 0 off, 1 in LDS,
                              // 2 in `pixel_cache_mem` (persistent kernel only, when LDS has no room)
     uint32_t* pixel_cache_mem;

@@ -475,7 +475,7 @@ DEV void traverse_flat2(const RenderArgs& a, uint32_t root_rec, bool cull, f3 lo
 // wgsl:292-296) and the caller's closest-hit update is order-free, so the result is the same.
 // Skipping a member whose root box is missed is the monotonicity argument of intersect_scene
 // (FOREST_CULLABLE members only, finite ray only).
-template <bool LDS, bool STATS, class Accept>
+template <bool LDS, bool STATS, bool SIMPLE, class Accept>
 DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_members, f3 lo, f3 ld, f3 inv,
                          uint32_t* stack, Accept&& accept, int& node_tests, int& tri_tests) {
     const bool finite_ray = rtm::abs_(inv.x) < INF && rtm::abs_(inv.y) < INF && rtm::abs_(inv.z) < INF &&
@@ -515,7 +515,7 @@ DEV void traverse_forest(const RenderArgs& a, uint32_t entry0, uint32_t n_member
                 cur = fbits(e.x);
                 cur_count = 0;
                 mesh = fbits(e.y);
-                cull = (fbits(e.z) & DMESH_GLASS) == 0u;
+                cull = SIMPLE || (fbits(e.z) & DMESH_GLASS) == 0u;
                 b.t = INF;
                 sp = 0;
                 have = true;
@@ -657,7 +657,7 @@ DEV void isect_spheres(const RenderArgs& a, f3 ro, f3 rd, Isect& I) {
 
 // Per-object outputs that only the overall winner needs (normals, uv) are computed once after
 // the loops from the same inputs, which yields the same bits.
-template <bool LDS>
+template <bool LDS, bool SIMPLE = false>
 DEV Hit isect_finish(const RenderArgs& a, const Isect& I, f3 ro, f3 rd) {
     Hit h;
     h.hit = I.any;
@@ -671,7 +671,7 @@ DEV Hit isect_finish(const RenderArgs& a, const Isect& I, f3 ro, f3 rd) {
     TIC(t9);
     if (I.any) {
         DIAG(11);
-        if (I.object >= 0) {
+        if (SIMPLE || I.object >= 0) {  // (SIMPLE: the scene has no spheres)
             const uint32_t mo = a.lay.mesh_off + (uint32_t)I.object * MESH_REC_BYTES;
             const uint32_t so = a.lay.shade_off + (I.win_tri & 0x7fffffffu) * TRI_SHADE_BYTES;
             const bool det_negative = (I.win_tri & 0x80000000u) != 0u;
@@ -710,14 +710,18 @@ DEV Hit isect_finish(const RenderArgs& a, const Isect& I, f3 ro, f3 rd) {
 }
 
 // wgsl:353-396 (+ ray_sphere :223-256).
-template <bool LDS, bool STATS, bool TLAS, bool PARK = false>
+// SIMPLE (few-mesh kernels only): the scene has no spheres, no glass and no textured material, and the camera no
+// jitter (RenderArgs::simple, decided by the host per launch) -- the instantiation BASELINE configs 2, 3 and 5 run.
+// The general code is the same code with those branches present; compiled out, they stop costing registers at the
+// kernels' 96-VGPR ceiling and instruction-cache space.
+template <bool LDS, bool STATS, bool TLAS, bool PARK = false, bool SIMPLE = false>
 DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int& node_tests,
                         int& tri_tests, Isect& I_parked) {
     // this lane's TLAS stack column sits behind the wave's BVH stack columns
     uint32_t* tstack = stack + stack_dwords(a);
     bool suspended = false;
     Isect I;
-    isect_spheres<LDS>(a, ro, rd, I);
+    if constexpr (!SIMPLE) isect_spheres<LDS>(a, ro, rd, I);
     // meshes (wgsl:369-393), as items: single meshes and top-level trees over mesh root boxes
     f3 lo{0, 0, 0}, ld{0, 0, 0}, inv{0, 0, 0};
     bool cull_ok = false;
@@ -779,7 +783,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         b.u = b.v = 0.0f;
         if (!TLAS && fbits(hdr.z) == 0u) flush_pending();  // (a BVH walk uses the stack column / is where the register pressure peaks)
         traverse_mesh<LDS, STATS>(a, fbits(hdr.y), fbits(hdr.z),
-                                  (flags & DMESH_GLASS) == 0, (flags & DMESH_DEEP) != 0, lo, ld, inv, stack, b,
+                                  SIMPLE || (flags & DMESH_GLASS) == 0, (flags & DMESH_DEEP) != 0, lo, ld, inv, stack, b,
                                   node_tests, tri_tests);
         if (b.tri != 0xffffffffu) {
             if (!TLAS && fbits(hdr.z) != 0u) offer_later(i, b);  // root leaf: the wave visits it in step
@@ -813,8 +817,8 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             // walk, where the register pressure peaks, was 7 more spilled dwords per lane: 95 MB of scratch write-back
             // per frame)
             flush_pending();
-            traverse_forest<LDS, STATS>(a, ia, __builtin_amdgcn_readfirstlane(fbits(item.w)), lo, ld, inv, stack,
-                                        accept_mesh_hit, node_tests, tri_tests);
+            traverse_forest<LDS, STATS, SIMPLE>(a, ia, __builtin_amdgcn_readfirstlane(fbits(item.w)), lo, ld, inv, stack,
+                                                accept_mesh_hit, node_tests, tri_tests);
             continue;
         }
         if constexpr (!TLAS) {
@@ -842,7 +846,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                 b.tri = 0xffffffffu;
                 b.u = b.v = 0.0f;
                 TIC(t18);
-                traverse_flat2<LDS, STATS>(a, __builtin_amdgcn_readfirstlane(fbits(hdr.y)), (fbits(hdr.x) & DMESH_GLASS) == 0, lo, ld, inv,
+                traverse_flat2<LDS, STATS>(a, __builtin_amdgcn_readfirstlane(fbits(hdr.y)), SIMPLE || (fbits(hdr.x) & DMESH_GLASS) == 0, lo, ld, inv,
                                            b, node_tests, tri_tests);
                 TOC(t18, 18);
                 if (b.tri != 0xffffffffu) offer_later(ia, b);
@@ -1007,7 +1011,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         h.suspended = true;
         return h;
     }
-    return isect_finish<LDS>(a, I, ro, rd);
+    return isect_finish<LDS, SIMPLE>(a, I, ro, rd);
 }
 
 // field byte offsets inside rt_material
@@ -1325,7 +1329,7 @@ enum : uint32_t {
     STEP_RESUME = 4,    // deferred walks: the segment's hit is the parked closest-hit record + the big mesh's walk
 };
 
-template <bool STATS>
+template <bool STATS, bool SIMPLE = false>
 DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve) {
     const int32_t nb = a.params.number_of_bounces;
     // Primary-ray memo.  With defocus_strength = diverge_strength = +0 (the default camera) the
@@ -1358,8 +1362,9 @@ DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32
             ColdArgs& ca = cold_args();
             const CameraConsts c = camera_consts(ca);
             float jx, jy, kx, ky;
-            disk_jitter(s.rng, ca.camera.defocus_strength, c.sx, jx, jy);
-            disk_jitter(s.rng, ca.camera.diverge_strength, c.sx, kx, ky);
+            // (SIMPLE: both strengths are +0 -- a pixel only gets here when a -0 is involved in its ray)
+            disk_jitter(s.rng, SIMPLE ? 0.0f : ca.camera.defocus_strength, c.sx, jx, jy);
+            disk_jitter(s.rng, SIMPLE ? 0.0f : ca.camera.diverge_strength, c.sx, kx, ky);
             s.ro = (c.origin + c.right * jx) + c.up * jy;
             const f3 focus = focus_point_of(ca, c, s.x, frame_row_of(ca, s.out_row));
             f3 jfp = (focus + c.right * kx) + c.up * ky;
@@ -1427,7 +1432,7 @@ DEV void memo_hit_store(const RenderArgs& a, const PixelState& s, uint32_t* ls, 
 }
 
 // LDS: material reads from LDS; TOTAL_LDS: the pixel sum lives in the lane's LDS state
-template <bool LDS, bool TOTAL_LDS>
+template <bool LDS, bool TOTAL_LDS, bool SIMPLE = false>
 DEV bool path_end(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t mode, const Hit& hit,
                   uint32_t& n_segments) {
     const int32_t nb = a.params.number_of_bounces;
@@ -1447,7 +1452,7 @@ DEV bool path_end(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t mod
             f3 rd = s.rd;
             f4 T = s.T;
             s.ro = hit.point;
-            if (flag == RT_MATERIAL_GLASS) {  // wgsl:414-436
+            if (!SIMPLE && flag == RT_MATERIAL_GLASS) {  // wgsl:414-436
                 DIAG(14);
                 if (hit.backface) {
                     const float4 ab = ld4<LDS>(a, mo + M_ABSORB);
@@ -1485,7 +1490,7 @@ DEV bool path_end(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t mod
                 s.light = s.light + emitted * T;
                 f4 color;
                 const int diffuse_index = ldi<LDS>(a, mo + M_DIFFUSE_IDX);
-                if (flag == RT_MATERIAL_TEXTURE && diffuse_index != -1) {
+                if (!SIMPLE && flag == RT_MATERIAL_TEXTURE && diffuse_index != -1) {
                     color = sample_texture(a, diffuse_index, hit.u, hit.v);
                 } else {
                     const float4 cc = ld4<LDS>(a, mo + M_COLOR);
@@ -1530,11 +1535,11 @@ template <bool TOTAL_LDS>
 DEV void park_store(const RenderArgs& a, uint32_t slot, const PixelState& s, uint32_t* ls, const Isect& I);
 DEV void park_load_hit(const RenderArgs& a, uint32_t slot, Isect& I, CompactHit& walked);
 
-template <bool LDS, bool STATS, bool TLAS, bool PARK = false>
+template <bool LDS, bool STATS, bool TLAS, bool PARK = false, bool SIMPLE = false>
 DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
                        bool& reused, int& node_tests, int& tri_tests, uint32_t resume_slot = 0xffffffffu) {
     // (a resumed pixel was parked behind path_begin: its segment has begun)
-    const uint32_t mode = PARK && resume_slot != 0xffffffffu ? (uint32_t)STEP_RESUME : path_begin<STATS>(a, s, ls, starve);
+    const uint32_t mode = PARK && resume_slot != 0xffffffffu ? (uint32_t)STEP_RESUME : path_begin<STATS, SIMPLE>(a, s, ls, starve);
     // segments served from the memo: the caller counts them per wave, OUTSIDE its `if (active)` (a ballot + a scalar
     // add with every lane of the wave present -- counted in here, under the divergent branch, the sum lived in the
     // active lanes only and was lost for every iteration lane 0 sat out)
@@ -1548,7 +1553,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
     } else if (mode == STEP_TRAVERSE) {
         TIC(t0);
         Isect I;
-        hit = intersect_scene<LDS, STATS, TLAS, PARK>(a, s.ro, s.rd, stack_of<total_in_lds(LDS)>(ls), node_tests, tri_tests, I);
+        hit = intersect_scene<LDS, STATS, TLAS, PARK, SIMPLE>(a, s.ro, s.rd, stack_of<total_in_lds(LDS)>(ls), node_tests, tri_tests, I);
         TOC(t0, 0);
         if constexpr (PARK && !TLAS) {
             if (a.park != 0u) {  // (wave-uniform)
@@ -1584,10 +1589,10 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
             world_hit<LDS>(a, a.lay.mesh_off + a.defer_mesh * MESH_REC_BYTES + 64u, lo, ld, s.ro, walked.t, whp, wdst);
             isect_offer(I, a.defer_mesh, walked, whp, wdst);
         }
-        hit = isect_finish<LDS>(a, I, s.ro, s.rd);
+        hit = isect_finish<LDS, SIMPLE>(a, I, s.ro, s.rd);
         memo_hit_store<STATS>(a, s, ls, hit);
     }
-    return path_end<LDS, total_in_lds(LDS)>(a, s, ls, mode, hit, n_segments) ? PATH_PIXEL_DONE : PATH_CONTINUE;
+    return path_end<LDS, total_in_lds(LDS), SIMPLE>(a, s, ls, mode, hit, n_segments) ? PATH_PIXEL_DONE : PATH_CONTINUE;
 }
 
 // Park records (rt_device.h): the whole state of a pixel between two segments.
@@ -1722,7 +1727,7 @@ DEV void flush_counters(const RenderArgs& a, uint32_t n_segments, uint32_t n_reu
 
 // Variant 1: one wave per 8x8 tile (the reference's dispatch shape), four
 // tiles per workgroup.
-template <bool LDS, bool STATS, bool TLAS>
+template <bool LDS, bool STATS, bool TLAS, bool SIMPLE>
 __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_kernel(const RenderArgs a) {
     uint32_t* ls = block_prologue<LDS>(a);
     const CameraConsts cam = camera_consts(a);
@@ -1740,7 +1745,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     int node_tests = 0, tri_tests = 0;
     while (__ballot(active) != 0ull) {
         bool reused = false;
-        if (active && path_step<LDS, STATS, TLAS>(a, s, ls, starve, n_segments, reused, node_tests, tri_tests) == PATH_PIXEL_DONE)
+        if (active && path_step<LDS, STATS, TLAS, false, SIMPLE>(a, s, ls, starve, n_segments, reused, node_tests, tri_tests) == PATH_PIXEL_DONE)
             active = false;
         n_reused_wave += (uint32_t)__popcll(__ballot(reused));  // (wave-uniform: every lane is here)
     }
@@ -1759,7 +1764,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
 // wave's current tile, so the wave stays full until the frame runs out.  The
 // per-pixel RNG stream depends only on the pixel's coordinates, so the image
 // does not depend on which lane rendered which pixel.
-template <bool LDS, bool STATS, bool TLAS, bool PARK>
+template <bool LDS, bool STATS, bool TLAS, bool PARK, bool SIMPLE>
 __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persistent_kernel(const RenderArgs a) {
 #if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
     const unsigned long long t_wave_start = __builtin_amdgcn_s_memrealtime();
@@ -1873,7 +1878,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         uint32_t step = PATH_CONTINUE;
         bool reused = false;
         if (active) {
-            step = path_step<LDS, STATS, TLAS, PARK>(a, s, ls, starve, n_segments, reused, node_tests, tri_tests, resume_slot);
+            step = path_step<LDS, STATS, TLAS, PARK, SIMPLE>(a, s, ls, starve, n_segments, reused, node_tests, tri_tests, resume_slot);
             resume_slot = 0xffffffffu;
             if (step == PATH_PIXEL_DONE) {
                 DIAG(16);
@@ -2280,21 +2285,26 @@ static void launch_k(K kernel, uint32_t blocks, size_t lds, hipStream_t stream, 
 template <bool LDS, bool TLAS>
 static void launch_variant(const RenderArgs& a, uint32_t ntiles, size_t lds, hipStream_t stream) {
     const uint32_t tile_blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    // the SIMPLE instantiations exist for the product kernels (no counters) of the few-mesh scenes
+    const bool simple = !TLAS && a.simple != 0u && a.count_tests == 0u;
     if (a.params.debug_flag != 0) {
         launch_k(rt_debug_kernel<LDS, TLAS>, tile_blocks, lds, stream, a);
     } else if (a.kernel_variant == 1) {
-        if (a.count_tests) launch_k(rt_render_tiles_kernel<LDS, true, TLAS>, tile_blocks, lds, stream, a);
-        else launch_k(rt_render_tiles_kernel<LDS, false, TLAS>, tile_blocks, lds, stream, a);
+        if (a.count_tests) launch_k(rt_render_tiles_kernel<LDS, true, TLAS, false>, tile_blocks, lds, stream, a);
+        else if (simple) launch_k(rt_render_tiles_kernel<LDS, false, TLAS, !TLAS>, tile_blocks, lds, stream, a);
+        else launch_k(rt_render_tiles_kernel<LDS, false, TLAS, false>, tile_blocks, lds, stream, a);
     } else {
         uint32_t blocks = a.persistent_blocks < tile_blocks ? a.persistent_blocks : tile_blocks;
         if (blocks == 0) blocks = 1;
         const bool park = !TLAS && (a.park != 0u || a.q_in != nullptr);  // a launch of a deferred-walk sequence
         if (park) {
-            if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS, !TLAS>, blocks, lds, stream, a);
-            else launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS>, blocks, lds, stream, a);
+            if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS, !TLAS, false>, blocks, lds, stream, a);
+            else if (simple) launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS, !TLAS>, blocks, lds, stream, a);
+            else launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS, false>, blocks, lds, stream, a);
         } else {
-            if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS, false>, blocks, lds, stream, a);
-            else launch_k(rt_render_persistent_kernel<LDS, false, TLAS, false>, blocks, lds, stream, a);
+            if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS, false, false>, blocks, lds, stream, a);
+            else if (simple) launch_k(rt_render_persistent_kernel<LDS, false, TLAS, false, !TLAS>, blocks, lds, stream, a);
+            else launch_k(rt_render_persistent_kernel<LDS, false, TLAS, false, false>, blocks, lds, stream, a);
         }
     }
 }

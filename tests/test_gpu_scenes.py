@@ -387,13 +387,15 @@ def test_random_many_mesh_scenes(rt, oracle, tracer, seed):
 
 @pytest.mark.parametrize("knobs", [{"forest": 0}, {"stack_wide": 1}, {"stack_wide": 0}, {"pixel_cache": 0}, {"pixel_cache": 2}, {"primary_table": 0},
                                    {"forest": 0, "stack_wide": 1, "pixel_cache": 2},
-                                   {"lds_top": -1}, {"lds_top": 1}, {"lds_top": 77}, {"lds_top": 2048}, {"flat2": 0}, {"flat2": 0, "forest": 0}],
+                                   {"lds_top": -1}, {"lds_top": 1}, {"lds_top": 77}, {"lds_top": 2048}, {"flat2": 0}, {"flat2": 0, "forest": 0},
+                                   {"specialise": 0}, {"specialise": 0, "kernel_variant": 1}, {"specialise": 1, "kernel_variant": 1}],
                          ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
 def test_tuning_knobs_do_not_change_the_bits(rt, oracle, tracer, cornell, dragon_arrays, knobs):
     """rt_set_option's contract: results never depend on the knobs (forest items, stack entry
     width, memo placement, the LDS-staged BVH top) -- on the LDS-resident Cornell scene and the
     global-memory dragon scene."""
-    defaults = {"forest": 1, "stack_wide": -1, "pixel_cache": 1, "primary_table": 1, "lds_top": 0, "flat2": 1}
+    defaults = {"forest": 1, "stack_wide": -1, "pixel_cache": 1, "primary_table": 1, "lds_top": 0, "flat2": 1, "specialise": 1,
+                "kernel_variant": -1}
     try:
         for name, value in knobs.items():
             tracer.set_option(name, value)
