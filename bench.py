@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the un-overlapped / first-frame measurements")
+    ap.add_argument("--no-per-frame-leg", action="store_true",
+                    help="skip the one-launch-per-frame leg after the timed region (profiling runs: one kind of launch only)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU-staged rehearsal on one GPU)")
@@ -227,20 +229,23 @@ def main():
         print(f"[verify] stitched frame bit-identical to 1-GPU frame: {same}", file=sys.stderr, flush=True)
         assert same
     rays_local, reused_local = float(st.segments), float(st.segments_reused)
+    launch_info = tracer.last_launch()                 # dynamic LDS per workgroup, grid, which instantiation ran
     launch_ms = st.kernel_ms / max(st.launches, 1)     # render (+ blend) launch, HIP events on the tracer's stream
     frames_per_launch = st.frames / max(st.launches, 1)
 
     # The same K frames once more with ONE launch (N > 1: and one gather + assemble) per frame: what a host that
     # presents every frame gets.  Outside the timed region of `value`; same barrier + synchronize bracket.
-    fence()
-    tracer.reset_timing()
-    t1 = time.perf_counter()
-    render(args.warmup + args.steps, args.steps, batch=1)
-    fence()
-    elapsed_pf = time.perf_counter() - t1
-    st_pf = tracer.stats()
-    rays_pf_local = float(st_pf.segments)
-    launch_ms_pf = st_pf.kernel_ms / max(st_pf.launches, 1)
+    elapsed_pf, rays_pf_local, launch_ms_pf = float("nan"), float("nan"), float("nan")
+    if not args.no_per_frame_leg:
+        fence()
+        tracer.reset_timing()
+        t1 = time.perf_counter()
+        render(args.warmup + args.steps, args.steps, batch=1)
+        fence()
+        elapsed_pf = time.perf_counter() - t1
+        st_pf = tracer.stats()
+        rays_pf_local = float(st_pf.segments)
+        launch_ms_pf = st_pf.kernel_ms / max(st_pf.launches, 1)
 
     if world > 1:
         t = torch.tensor([elapsed, rays_local, launch_ms, reused_local, elapsed_pf, rays_pf_local, launch_ms_pf], dtype=torch.float64,
@@ -349,17 +354,18 @@ def main():
         # which kernel the library runs for this shape (rt_api.hip render_impl): batches always the persistent one
         cus = torch.cuda.get_device_properties(device).multi_processor_count
         tiles = ((W + 7) // 8) * (texels // W // 8 if world > 1 else (H + 7) // 8)
-        kernel = "rt_render_persistent_kernel<true, false, false>"
-        if frames_per_launch == 1 and (args.variant == 1 or (args.variant is None and tiles * 4 <= cus * 20 * 5)):
-            kernel = "rt_render_tiles_kernel<true, false, false>"
+        spec = "true" if launch_info["specialised"] else "false"
+        kernel = f"rt_render_persistent_kernel<true, false, false, false, {spec}>"
+        if launch_info["one_wave_per_tile"]:
+            kernel = f"rt_render_tiles_kernel<true, false, false, {spec}>"
         out = {
             "metric": "Mrays/s", "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             # the two launch modes under explicit names (value == value_batched when --batch > 1)
             "value_batched": mrays if frames_per_launch > 1 else None,
-            "value_per_frame_launch": rays_pf / elapsed_pf / 1e6,
+            "value_per_frame_launch": None if args.no_per_frame_leg else rays_pf / elapsed_pf / 1e6,
             "ms_per_frame_batched": ms_per_step if frames_per_launch > 1 else None,
-            "ms_per_frame_per_launch": elapsed_pf / args.steps * 1e3,
+            "ms_per_frame_per_launch": None if args.no_per_frame_leg else elapsed_pf / args.steps * 1e3,
             "value_definition": f"value = rays of {args.steps} frames / wall time with {frames_per_launch:g} frames per launch "
                                 "(intermediate frames of a batch are not observable); value_per_frame_launch = the same frames "
                                 "with one launch" + (" and one gather" if world > 1 else "") + " per frame, timed right after",
@@ -385,6 +391,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src or stale,
                          "kernel": kernel, "kernel_ms": launch_ms, "frames_per_launch": frames_per_launch,
+                         "launch": launch_info,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "path is FP32-VALU-bound (SURVEY 8d, DESIGN.md): compulsory HBM bytes are 32 B per pixel per frame; "
                                  "kernel_ms is the launch (render + ordered blend of the batch) from HIP events on the "

@@ -265,6 +265,11 @@ int rt_write_image(rt_handle* h, const float* rgba32f_in, size_t bytes);
 
 int rt_synchronize(rt_handle* h);
 int rt_get_stats(rt_handle* h, rt_stats* out);
+/* Shape of the last render launch (what a profile summary needs next to the code object's static resources):
+ * out[0] = dynamic LDS bytes per workgroup, out[1] = workgroups of the render kernel, out[2] = 1 when the scene blob
+ * was staged into LDS, out[3] = bit 0: many-mesh kernels, bit 1: specialised instantiation, bit 2: one-wave-per-tile
+ * variant, bit 3: a deferred-walk sequence ran. */
+int rt_last_launch(rt_handle* h, uint32_t out[4]);
 /* Zero the counters and forget the recorded launch times. */
 int rt_reset_timing(rt_handle* h);
 /* Run this handle's work on a caller-owned HIP stream (e.g. the stream a
@@ -274,18 +279,47 @@ int rt_set_stream(rt_handle* h, void* hip_stream);
 /* Render into caller-owned device memory of `texels` RGBA32F texels (e.g. a
  * buffer a collective library will send); NULL restores the internal image. */
 int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
-/* Tuning knobs (results never depend on them): "kernel_variant" -1 = auto
- * (default), 0 = persistent waves with active-lane refill, 1 = one wave per 8x8 tile;
- * "persistent_blocks" = grid size of variant 0 (256-thread workgroups);
- * "lds_scene" 0 = never stage the scene into LDS; "cull_roots" -1 auto / 0 / 1 =
- * results-preserving root-box culling of meshes in the mesh loop; "tlas" 0 = no top-level
- * trees over mesh root boxes, "tlas_min" = smallest run of meshes that gets one (both take
- * effect at the next rt_upload_scene); "pixel_cache" 0 = no per-pixel memoisation of the
- * primary ray and its hit, 1 = memo in LDS when it fits (default), 2 = memo in global memory;
- * "vote_eighths" (0..8, default 6) and
- * "vote_patience" (default 3) = the intersection vote of the render kernels; "tile_feedback" 0 = do not
- * reorder tiles by an earlier frame's per-tile ray counts, "tile_feedback_period" = frames an order is kept (default 8); "batch_frames" = frames per launch of rt_render_frames (1..32, default 16); "batch_tile_major" 1 (default) = a batch's work items in (tile, frame) order: a tile's frames are handed out back to back, so the lanes of a wave work on the same image region, 0 = frame by frame; "multi_rccl" = gather transport of rt_render_multi (see there); "lds_top" 0 (default) / -1 what fits at full occupancy / N = wide BVH records of the biggest mesh staged into LDS by every workgroup when the scene itself is read from global memory (its first levels, numbered breadth-first at upload); "sort_rounds" -1 (default: automatic) / 0 off / 1..64 = deferred walks on scenes with one big mesh among a few: a render launch parks a pixel in front of every entry of a ray into the big mesh, a walk kernel walks the mesh for all parked rays at once, the next render launch resumes them, for that many rounds (same image, bit for bit; automatic = by the work of the launch in units of one 1920x1080 frame at 16 samples per pixel and the size of the big mesh: 3 to 12 rounds from 8 units (from 2 units, 2 rounds, for a mesh of 400 k BVH nodes and more), none below, and only while the two park queues -- 224 bytes per pixel and frame of the batch, each -- fit a quarter of the free device memory); "defer_min_nodes" (default 1024; next upload) = the smallest BVH, in internal nodes, whose mesh may be the deferred one; "primary_table" 0 = compute the memoised primary ray per pixel in the render kernel instead of once per (camera, frame size); "forest" 0 = no forest items (next
- * upload); "flat2" 0 = meshes whose BVH is a root with two leaves are walked like any other mesh instead of as straight-line code (next upload); "stack_wide" -1 auto / 0 one-dword BVH stack entries whenever legal / 1 two-dword entries. */
+/* Tuning knobs.  The image, the ray count and the test counters NEVER depend on them (every option is swept by the
+ * parity tests); they choose between schedules and data placements.  Unknown names and out-of-range values return
+ * RT_ERR_INVALID_ARGUMENT.  "(upload)" = takes effect at the next rt_upload_scene.
+ *
+ *   name                  values (default)        meaning
+ *   --------------------  ----------------------  ---------------------------------------------------------------
+ *   kernel_variant        -1 / 0 / 1 (-1)         -1 automatic; 0 persistent waves with active-lane refill; 1 one wave
+ *                                                 per 8x8 tile (chosen automatically at <= 1.25 tiles per resident wave)
+ *   persistent_blocks     >= 1 (CUs x 5)          grid of variant 0 (256-thread workgroups)
+ *   specialise            0 / 1 (1)               1: scenes without spheres, glass and textured materials, rendered by a
+ *                                                 camera without jitter, run kernels with those branches compiled out
+ *   lds_scene             0 / 1 (1)               0: never stage the scene blob into LDS
+ *   pixel_cache           0 / 1 / 2 (1)           per-pixel memo of the primary ray and its hit: off / in LDS when it
+ *                                                 fits (else global memory) / always in global memory
+ *   primary_table         0 / 1 (1)               0: compute the memoised primary ray per pixel in the render kernel
+ *                                                 instead of once per (camera, frame size)
+ *   vote_eighths          0..8 (6)                intersection vote: traverse when wanting lanes x 8 >= lanes x this
+ *   vote_patience         >= 0 (3)                ... or when some lane has waited this many iterations
+ *   tile_feedback         0 / 1 (1)               order the tiles by an earlier frame's rays per tile, heaviest first
+ *   tile_feedback_period  >= 1 (8)                frames an order is kept before it is refreshed
+ *   batch_frames          1..32 (16)              frames per launch of rt_render_frames
+ *   batch_tile_major      0 / 1 (1)               a batch's work items in (tile, frame) order instead of (frame, tile)
+ *   forest                0 / 1 (1)  (upload)     BVH meshes of one local space walked per lane back to back
+ *   flat2                 0 / 1 (1)  (upload)     meshes whose BVH is a root with two leaves run as straight-line code
+ *   stack_wide            -1 / 0 / 1 (-1)         BVH stack entries: automatic / one dword when legal / two dwords
+ *   tlas                  0 / 1 (1)  (upload)     top-level trees over the root boxes of many meshes in one local space
+ *   tlas_min              >= 2 (8)   (upload)     smallest run of meshes that gets a top-level tree
+ *   cull_roots            -1 / 0 / 1 (-1)         results-preserving root-box culling in the mesh loop (-1: from 16 meshes)
+ *   lds_top               -1 / 0 / N (0)          wide BVH records of the biggest mesh staged into LDS when the scene is read
+ *                                                 from global memory: what fits at full occupancy / none / N (<= 2048)
+ *   lds_tlas              0 / 1 (see DESIGN)      top-level tree records staged into LDS when the scene is read from
+ *                                                 global memory
+ *   sort_rounds           -1 / 0 / 1..64 (-1)     deferred walks (one big mesh among a few): park pixels in front of the
+ *                                                 mesh, walk it for all parked rays in a kernel of its own, resume --
+ *                                                 for that many rounds; -1: by the work of the launch and the mesh's size,
+ *                                                 and only while both park queues fit a quarter of the free memory
+ *   defer_min_nodes       >= 1 (1024) (upload)    smallest BVH (internal nodes) whose mesh may be the deferred one
+ *   multi_rccl            0 / 1 / 2 (1)           gather of rt_render_multi: device-to-device copies / RCCL between
+ *                                                 distinct devices, copies otherwise (falls back to copies when librccl
+ *                                                 cannot be loaded) / RCCL or an error
+ */
 int rt_set_option(rt_handle* h, const char* name, int value);
 /* Enable/disable the optional per-ray counters (node/triangle tests). */
 int rt_set_counters(rt_handle* h, int enabled);

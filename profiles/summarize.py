@@ -30,6 +30,52 @@ def rows(pat):
     return list(csv.DictReader(open(files[-1]))) if files else []
 
 
+def code_object_resources():
+    """Registers, scratch and static LDS of every kernel, from the gfx950 code object's metadata (what the ISA really
+    uses: the per-dispatch VGPR_Count / LDS_Block_Size columns of rocprofv3's kernel trace are allocation granules and
+    the STATIC LDS only -- they read `48` and `0` for a kernel with 96 VGPRs and 30 KB of dynamic LDS).  Compiles the
+    device code to assembly with the product flags (a minute or two; no GPU needed).  Returns {demangled name: dict}."""
+    import re
+    import subprocess
+    import tempfile
+    root = os.path.dirname(HERE)
+    out = {}
+    with tempfile.TemporaryDirectory() as t:
+        asm = os.path.join(t, "k.s")
+        cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+               "-fno-slp-vectorize", "-I", os.path.join(root, "include"), "--cuda-device-only", "-S",
+               os.path.join(root, "ray_tracer_2_amd", "csrc", "rt_kernel.hip"), "-o", asm]
+        if subprocess.run(cmd, capture_output=True).returncode != 0:
+            return out
+        text = open(asm).read()
+    md = text[text.index("amdhsa.kernels:"):]
+    for ent in md.split("  - .agpr_count:")[1:]:
+        g = lambda k: re.search(rf"\.{k}:\s+(\S+)", ent).group(1)
+        name = g("name")
+        dem = name
+        for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+            try:
+                dem = subprocess.run([tool, name], capture_output=True, text=True).stdout.strip() or name
+                break
+            except OSError:
+                continue
+        out[dem.replace(" ", "")] = {"vgpr": int(g("vgpr_count")), "sgpr": int(g("sgpr_count")), "scratch": int(g("private_segment_fixed_size")),
+                                     "static_lds": int(g("group_segment_fixed_size")), "agpr": int(ent.split()[0])}
+    return out
+
+
+def bench_line(d):
+    """The JSON line bench.py printed during the trace pass (its stdout is in <dir>/trace.log), if the profiled
+    command was bench.py."""
+    try:
+        for l in reversed(open(f"{d}/trace.log").read().splitlines()):
+            if l.startswith("{") and '"metric"' in l:
+                return json.loads(l)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
@@ -37,6 +83,7 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=16)
     ap.add_argument("--note", default="")
     ap.add_argument("--demand-json", default="", help="tools/bench_scene.py BS_JSON output: demand bytes per segment from the stats counters")
+    ap.add_argument("--no-resources", action="store_true", help="skip the code-object resource table (needs hipcc)")
     ap.add_argument("--no-latest", action="store_true", help="do not rewrite profiles/latest_traffic.json (not the headline config)")
     ap.add_argument("--total-frames", type=int, default=0,
                     help="frames rendered by the whole run (warm-up included): adds a section with the sums over ALL render / walk / "
@@ -64,8 +111,22 @@ def main():
     dur = lambda rs: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs) / max(len(rs), 1) * 1e-9
     if tr:
         r = tr[-1]
-        lines.append(f"render kernel: grid {r['Grid_Size_X']} x wg {r['Workgroup_Size_X']}, VGPR_Count {r['VGPR_Count']}, "
-                     f"SGPR_Count {r['SGPR_Count']}, LDS_Block_Size {r['LDS_Block_Size']}, Scratch_Size {r['Scratch_Size']}")
+        res = {} if args.no_resources else code_object_resources()
+        lines.append(f"render kernel: {render_name}")
+        lines.append(f"  launch: grid {r['Grid_Size_X']} work-items = {int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])} workgroups x {r['Workgroup_Size_X']}")
+        for name in sorted(set(x["Kernel_Name"] for x in trace if "rt_" in x["Kernel_Name"])):
+            cr = res.get(name.replace(" ", ""))
+            if cr:
+                lines.append(f"  code object: {cr['vgpr']:3d} VGPRs, {cr['agpr']} AGPRs, {cr['sgpr']:3d} SGPRs, {cr['scratch']:3d} B scratch per lane, "
+                             f"{cr['static_lds']} B static LDS   {name[:90]}")
+        bl_json = bench_line(d)
+        if bl_json and "launch" in bl_json.get("roofline", {}):
+            ll = bl_json["roofline"]["launch"]
+            lines.append(f"  dynamic LDS of the render launch (rt_last_launch): {ll['lds_bytes_per_workgroup']} B per workgroup, "
+                         f"{ll['workgroups']} workgroups, scene staged in LDS: {ll['scene_in_lds']}, specialised instantiation: {ll['specialised']}")
+        lines.append(f"  (rocprofv3's per-dispatch columns, for the record: VGPR_Count {r['VGPR_Count']}, Accum_VGPR_Count {r.get('Accum_VGPR_Count', '?')}, "
+                     f"SGPR_Count {r['SGPR_Count']}, LDS_Block_Size {r['LDS_Block_Size']}, Scratch_Size {r['Scratch_Size']} -- allocation "
+                     "granules / static LDS only, not the figures above)")
         steady = tr[1:] if len(tr) > 2 else tr
         lines.append(f"render kernel, launches after the first: avg {dur(steady) * 1e6:.1f} us per launch = "
                      f"{dur(steady) * 1e6 / args.frames_per_launch:.1f} us per frame ({args.frames_per_launch} frames per launch)"

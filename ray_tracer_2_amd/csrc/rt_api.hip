@@ -152,6 +152,7 @@ struct rt_handle {
     int tlas_min = (int)TLAS_MIN_MESHES;  // option "tlas_min": smallest run of meshes that gets a top-level tree
     rt_camera_uniform camera{};
     int count_tests = 0;
+    uint32_t last_launch[4] = {0, 0, 0, 0};  // rt_last_launch
     std::string err;
 };
 
@@ -1230,6 +1231,14 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             h->ev_pool.emplace_back(s0, s1);
         }
     }
+    {
+        const uint32_t tile_blocks = (n_tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+        h->last_launch[0] = (uint32_t)render_lds_bytes(a);
+        h->last_launch[1] = a.kernel_variant == 1 || params->debug_flag != 0 ? tile_blocks : std::min(a.persistent_blocks, tile_blocks);
+        h->last_launch[2] = a.lds_scene;
+        h->last_launch[3] = (a.many_mesh ? 1u : 0u) | ((a.simple && !a.many_mesh && !a.count_tests) ? 2u : 0u) |
+                            (a.kernel_variant == 1 ? 4u : 0u) | (rounds ? 8u : 0u);
+    }
     auto& ev = h->ev_pool[h->ev_used++];
     HIP_TRY(h, hipEventRecord(ev.first, h->stream));
     if (!rounds) {
@@ -1580,6 +1589,12 @@ int rt_get_stats(rt_handle* h, rt_stats* out) {
     out->kernel_ms = (float)total;
     out->launches = (uint32_t)h->launches_total;
     out->frames = (uint32_t)h->frames_total;
+    return RT_OK;
+}
+
+int rt_last_launch(rt_handle* h, uint32_t out[4]) {
+    if (!h || !out) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    for (int k = 0; k < 4; ++k) out[k] = h->last_launch[k];
     return RT_OK;
 }
 

@@ -142,6 +142,14 @@ class RayTracer:
         self._check(self._L.rt_get_stats(self._h, C.byref(s)))
         return s
 
+    def last_launch(self):
+        """Shape of the last render launch: dynamic LDS bytes per workgroup, workgroups, scene staged in LDS, kernel flags."""
+        out = (C.c_uint32 * 4)()
+        self._check(self._L.rt_last_launch(self._h, C.byref(out)))
+        return {"lds_bytes_per_workgroup": out[0], "workgroups": out[1], "scene_in_lds": bool(out[2]),
+                "many_mesh": bool(out[3] & 1), "specialised": bool(out[3] & 2), "one_wave_per_tile": bool(out[3] & 4),
+                "deferred_walks": bool(out[3] & 8)}
+
     @property
     def device_image_ptr(self):
         return self._L.rt_device_image(self._h)
