@@ -309,8 +309,9 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *   cull_roots            -1 / 0 / 1 (-1)         results-preserving root-box culling in the mesh loop (-1: from 16 meshes)
  *   lds_top               -1 / 0 / N (0)          wide BVH records of the biggest mesh staged into LDS when the scene is read
  *                                                 from global memory: what fits at full occupancy / none / N (<= 2048)
- *   lds_tlas              0 / 1 (see DESIGN)      top-level tree records staged into LDS when the scene is read from
- *                                                 global memory
+ *   lds_tlas              0 / 1 / 2 (0)           top-level tree records staged into LDS when the scene is read from global
+ *                                                 memory: none / the top levels that fit at full occupancy / the whole tree
+ *                                                 (measured slower both ways)
  *   sort_rounds           -1 / 0 / 1..64 (-1)     deferred walks (one big mesh among a few): park pixels in front of the
  *                                                 mesh, walk it for all parked rays in a kernel of its own, resume --
  *                                                 for that many rounds; -1: by the work of the launch and the mesh's size,

@@ -90,6 +90,13 @@ struct rt_handle {
     // option "lds_top": 0 off (default: measured slower), -1 what fits beside the stacks at full
     // occupancy, N records
     int lds_top = 0;
+    // option "lds_tlas": top-level tree records staged into LDS when the scene is read from global memory: 0 off,
+    // 1 when they fit beside the stacks without costing a workgroup per CU, 2 always (if they fit the LDS at all)
+    // (default 0: measured slower both ways on the sponza-sized stand-in, DESIGN.md section 5.4 -- the whole tree costs
+    // two workgroups per CU, 10.64 -> 13.47 ms; the 42 top records that fit at full occupancy make every tree fetch a
+    // two-path load, 10.67 -> 11.98 ms)
+    int lds_tlas = 0;
+    uint32_t n_tlas_records = 0;
     float4* own_image = nullptr;  // allocated by rt_create; `image` may be rebound
     float4* multi_gathered = nullptr;  // rt_render_multi root: [world][pad_texels]
     float4* multi_frame = nullptr;     // rt_render_multi root: assembled full frame
@@ -680,6 +687,32 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             }
             i0 = i1;
         }
+        // Number the tree records breadth-first from the roots (all trees together): any prefix of the array is then
+        // "the top levels", which is what option "lds_tlas" stages into LDS when the whole tree does not fit.
+        if (!tlas.empty()) {
+            std::vector<uint32_t> order, new_of(tlas.size(), 0xffffffffu);
+            auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+            for (const Item& it : items)
+                if (it.kind & ITEM_TLAS) order.push_back(it.a);
+            for (size_t q = 0; q < order.size(); ++q) {
+                const WideRec& w = tlas[order[q]];
+                if (bits(w.q[1].w) == 0u) order.push_back(bits(w.q[1].z));  // child a is a tree node
+                if (bits(w.q[3].w) == 0u) order.push_back(bits(w.q[3].z));
+            }
+            if (order.size() == tlas.size()) {
+                for (size_t q = 0; q < order.size(); ++q) new_of[order[q]] = (uint32_t)q;
+                std::vector<WideRec> re(tlas.size());
+                for (size_t q = 0; q < order.size(); ++q) {
+                    WideRec w = tlas[order[q]];
+                    if (bits(w.q[1].w) == 0u) w.q[1].z = asf2(new_of[bits(w.q[1].z)]);
+                    if (bits(w.q[3].w) == 0u) w.q[3].z = asf2(new_of[bits(w.q[3].z)]);
+                    re[q] = w;
+                }
+                tlas.swap(re);
+                for (Item& it : items)
+                    if (it.kind & ITEM_TLAS) it.a = new_of[it.a];
+            }
+        }
         // (one entry is always there: the many-mesh kernels, which the debug views use too,
         // run single meshes through the same stack)
         const uint32_t tlas_entries = tlas.empty() ? 1u : tlas_depth + 2u;
@@ -824,6 +857,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         }
         h->tlas_entries = tlas_entries;
         h->has_tlas = has_tlas;
+        h->n_tlas_records = (uint32_t)tlas.size();
         h->has_forest = !forest_entries.empty();
         {
             bool plain = n_spheres == 0;
@@ -948,6 +982,9 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "lds_top") {
         if (value < -1 || value > 2048) return fail(h, RT_ERR_INVALID_ARGUMENT, "lds_top must be -1 (auto), 0 (off) or a record count <= 2048");
         h->lds_top = value;
+    } else if (n == "lds_tlas") {
+        if (value < 0 || value > 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "lds_tlas must be 0 (off), 1 (when it costs no occupancy) or 2 (whenever it fits)");
+        h->lds_tlas = value;
     } else if (n == "multi_rccl") {
         if (value < 0 || value > 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "multi_rccl must be 0 (peer copies), 1 (RCCL between distinct devices) or 2 (RCCL always)");
         h->multi_rccl = value;
@@ -1089,6 +1126,19 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         uint32_t fit = used < LDS_BUDGET_BYTES ? (uint32_t)((LDS_BUDGET_BYTES - used) / WIDE_REC_BYTES) : 0u;
         if (h->lds_top > 0) fit = (uint32_t)h->lds_top;
         a.top_count = std::min(fit, h->top_available);
+    }
+    a.tlas_lds = 0;
+    if (!a.lds_scene && a.many_mesh && h->has_tlas && h->lds_tlas != 0 && params->debug_flag == 0) {
+        // 1: as many of the breadth-first numbered records (the top levels first) as fit without costing a workgroup per
+        // CU; 2: the whole tree if the LDS can hold it at all
+        const size_t used = render_lds_bytes(a), need = (size_t)h->n_tlas_records * WIDE_REC_BYTES;
+        const uint32_t per_cu_now = std::min<uint32_t>(BLOCKS_PER_CU, (uint32_t)((160u * 1024u) / (used ? used : 1)));
+        const size_t room = (160u * 1024u) / per_cu_now > used ? (160u * 1024u) / per_cu_now - used : 0;
+        if (h->lds_tlas == 2) {
+            if (used + need <= 64u * 1024u) a.tlas_lds = h->n_tlas_records;
+        } else {
+            a.tlas_lds = std::min<uint32_t>(h->n_tlas_records, (uint32_t)(room / WIDE_REC_BYTES));
+        }
     }
     a.persistent_blocks = h->persistent_blocks;
     {

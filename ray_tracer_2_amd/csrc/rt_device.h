@@ -190,6 +190,10 @@ struct RenderArgs {
     // top_base + top_count - 1 -- the first levels of the biggest mesh, numbered breadth-first at upload
     // -- are copied into LDS by every workgroup (coalesced 16-byte loads) and read from there.
     uint32_t top_base, top_count;
+    // LDS-staged top-level tree (many-mesh scenes read from global memory; option "lds_tlas"): all tlas_lds wide
+    // records of the scene's top-level tree(s) are copied into LDS by every workgroup, behind the staged BVH top;
+    // 0 = read in place.
+    uint32_t tlas_lds;
     // Deferred walks (option "sort_rounds"; scenes with one big mesh, few-mesh kernels).  The walk through a big
     // mesh is entered by a few lanes of a wave at a time and costs the whole wave its full length.  With park != 0
     // a render launch does not walk that mesh (its item, ITEM_DEFER, is the last of the mesh loop -- the order of the

@@ -231,6 +231,23 @@ DEV void load_wide(const RenderArgs& a, uint32_t idx, float4& q0, float4& q1, fl
     }
 }
 
+// Top-level tree record `e` (many-mesh kernels): from the staged scene, from the LDS-staged copy of the tree
+// (RenderArgs::tlas_lds: scenes read from global memory whose tree fits beside the stacks), or from global memory.
+DEV uint32_t tlas_lds_off16(const RenderArgs& a);
+template <bool LDS>
+DEV void load_tlas(const RenderArgs& a, uint32_t e, float4& q0, float4& q1, float4& q2, float4& q3) {
+    if constexpr (LDS) {
+        const uint32_t wo = a.lay.tlas_off + e * WIDE_REC_BYTES;
+        q0 = ld4<true>(a, wo); q1 = ld4<true>(a, wo + 16); q2 = ld4<true>(a, wo + 32); q3 = ld4<true>(a, wo + 48);
+    } else if (e < a.tlas_lds) {  // (the first tlas_lds records -- the top levels, numbered breadth-first -- are staged)
+        const float4* p = lds_mem + tlas_lds_off16(a) + e * 4u;
+        q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+    } else {
+        const uint32_t wo = a.lay.tlas_off + e * WIDE_REC_BYTES;
+        q0 = ld4<false>(a, wo); q1 = ld4<false>(a, wo + 16); q2 = ld4<false>(a, wo + 32); q3 = ld4<false>(a, wo + 48);
+    }
+}
+
 // (mat4 * vec4(v, w)).xyz with the four columns as float4
 DEV f3 mat_cols_xyz(float4 c0, float4 c1, float4 c2, float4 c3, f3 v, float w) {
     f3 r;
@@ -938,9 +955,8 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                                 have = true;
                             } else {
                                 DIAG(17);
-                                const uint32_t wo = a.lay.tlas_off + e * WIDE_REC_BYTES;
-                                const float4 q0 = ld4<LDS>(a, wo), q1 = ld4<LDS>(a, wo + 16), q2 = ld4<LDS>(a, wo + 32),
-                                             q3 = ld4<LDS>(a, wo + 48);
+                                float4 q0, q1, q2, q3;
+                                load_tlas<LDS>(a, e, q0, q1, q2, q3);
                                 const bool hit_a = !cull_ok || aabb_dist(lo, inv, q0, q1, INF) < INF;
                                 const bool hit_b = !cull_ok || aabb_dist(lo, inv, q2, q3, INF) < INF;
                                 if (hit_b) {
@@ -1121,6 +1137,7 @@ DEV uint32_t wave_region_dwords(const RenderArgs& a) {
 }
 
 DEV uint32_t top_lds_off16(const RenderArgs& a) { return (WAVES_PER_BLOCK * wave_region_dwords(a) + WAVES_PER_BLOCK * 8u * 3u) >> 2; }
+DEV uint32_t tlas_lds_off16(const RenderArgs& a) { return top_lds_off16(a) + a.top_count * 4u; }
 
 // Stage the scene blob into LDS (coalesced 16-byte loads, whole workgroup) and
 // return this lane's base pointer (its lane state; see the map above).
@@ -1132,10 +1149,13 @@ DEV uint32_t* block_prologue(const RenderArgs& a) {
         for (uint32_t i = threadIdx.x; i < n16; i += BLOCK_THREADS) lds_mem[i] = a.blob[i];
         __syncthreads();
         base = n16;
-    } else if (a.top_count != 0u) {
+    } else if (a.top_count != 0u || a.tlas_lds != 0u) {
         // the top of the big mesh's BVH: top_count consecutive wide records
         const uint32_t src = (a.lay.wide_off + a.top_base * WIDE_REC_BYTES) >> 4, dst = top_lds_off16(a);
         for (uint32_t i = threadIdx.x; i < a.top_count * 4u; i += BLOCK_THREADS) lds_mem[dst + i] = a.blob[src + i];
+        // the top-level tree(s): tlas_lds consecutive wide records (every ray's first dependent fetches)
+        const uint32_t tsrc = a.lay.tlas_off >> 4, tdst = tlas_lds_off16(a);
+        for (uint32_t i = threadIdx.x; i < a.tlas_lds * 4u; i += BLOCK_THREADS) lds_mem[tdst + i] = a.blob[tsrc + i];
         __syncthreads();
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -2271,7 +2291,8 @@ size_t render_lds_bytes(const RenderArgs& a) {
     size_t lane_state = total_in_lds(a.lds_scene != 0u) ? (size_t)LANE_STATE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
     size_t cache = a.pixel_cache == 1u ? (size_t)PIXEL_MEMO_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
     // (= 4 x wave_region_dwords + the cost tables, see the LDS map)
-    return stacks + cost_tables + lane_state + cache + (a.lds_scene ? a.lay.bytes : (size_t)a.top_count * WIDE_REC_BYTES);
+    return stacks + cost_tables + lane_state + cache +
+           (a.lds_scene ? a.lay.bytes : ((size_t)a.top_count + a.tlas_lds) * WIDE_REC_BYTES);
 }
 
 // Dynamic LDS above 64 KiB (deep-BVH stacks) has to be opted into per kernel.

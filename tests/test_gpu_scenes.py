@@ -656,6 +656,20 @@ def test_config4_sponza_sized_standin(rt, oracle, tracer):
         assert (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests)
     tracer.set_option("kernel_variant", -1)
     tracer.set_option("tlas", 1)
+    # option lds_tlas: the tree's top levels (1) or the whole tree (2) staged into LDS -- same bits, same counters
+    try:
+        for staged in (1, 2):
+            tracer.set_option("lds_tlas", staged)
+            for counters in (True, False):
+                tracer.set_counters(counters)
+                gpu, _, s, _ = render_both(rt, oracle, tracer, a, p)
+                assert same(gpu, ref), (staged, counters)
+                assert s.segments == st.segments
+                if counters:
+                    assert (s.node_tests, s.triangle_tests) == (st.node_tests, st.triangle_tests)
+    finally:
+        tracer.set_counters(False)
+        tracer.set_option("lds_tlas", 0)
     acc = np.zeros((90, 160, 4), np.float32)
     for f in range(3):
         p.frames = f

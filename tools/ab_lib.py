@@ -56,7 +56,7 @@ def child(a):
     run(max(a.batch, 8), a.frames)
     st = tr.stats()
     print(json.dumps({"ms_per_frame": st.kernel_ms / st.frames, "segments_per_frame": st.segments / st.frames,
-                      "launches": st.launches}), flush=True)
+                      "launches": st.launches, "launch": tr.last_launch() if hasattr(tr, "last_launch") else None}), flush=True)
     tr.close()
 
 
@@ -78,7 +78,7 @@ def main():
         return child(a)
     libs = a.libs or [os.path.join(ROOT, "ray_tracer_2_amd", "librt2_mi355x.so")]
     times = {l: [] for l in libs}
-    segs = {}
+    segs, info = {}, {}
     for r in range(a.rounds):
         for l in libs:
             path, _, own = l.partition(":")
@@ -93,10 +93,11 @@ def main():
             d = json.loads(out.stdout.strip().splitlines()[-1])
             times[l].append(d["ms_per_frame"])
             segs[l] = d["segments_per_frame"]
+            info[l] = d.get("launch")
     print(f"scene {a.scene} {a.w}x{a.h} {a.spp} spp {a.bounces} bounces, {a.batch} frames per launch, {a.frames} frames x {a.rounds} rounds")
     for l in libs:
         if times[l]:
-            print(f"{os.path.basename(l):60s} median {statistics.median(times[l]):8.4f}  min {min(times[l]):8.4f} ms/frame   rays/frame {segs[l]:.0f}", flush=True)
+            print(f"{os.path.basename(l):60s} median {statistics.median(times[l]):8.4f}  min {min(times[l]):8.4f} ms/frame   rays/frame {segs[l]:.0f}  {info.get(l)}", flush=True)
 
 
 if __name__ == "__main__":
