@@ -268,7 +268,7 @@ int rt_get_stats(rt_handle* h, rt_stats* out);
 /* Shape of the last render launch (what a profile summary needs next to the code object's static resources):
  * out[0] = dynamic LDS bytes per workgroup, out[1] = workgroups of the render kernel, out[2] = 1 when the scene blob
  * was staged into LDS, out[3] = bit 0: many-mesh kernels, bit 1: specialised instantiation, bit 2: one-wave-per-tile
- * variant, bit 3: a deferred-walk sequence ran. */
+ * variant, bit 3: a deferred-walk sequence ran, bit 4: a wavefront sequence ran (then out[0] / out[1] are the walk kernel's). */
 int rt_last_launch(rt_handle* h, uint32_t out[4]);
 /* Zero the counters and forget the recorded launch times. */
 int rt_reset_timing(rt_handle* h);
@@ -317,6 +317,9 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 for that many rounds; -1: by the work of the launch and the mesh's size,
  *                                                 and only while both park queues fit a quarter of the free memory
  *   defer_min_nodes       >= 1 (1024) (upload)    smallest BVH (internal nodes) whose mesh may be the deferred one
+ *   wavefront             0 / 1 (0)               wavefront sequences (many-mesh scenes): path state in memory slots, a shading
+ *                                                 kernel and a ray-walk kernel with per-lane refill alternate (measured slower
+ *                                                 than the inline kernels: DESIGN.md section 5.5)
  *   multi_rccl            0 / 1 / 2 (1)           gather of rt_render_multi: device-to-device copies / RCCL between
  *                                                 distinct devices, copies otherwise (falls back to copies when librccl
  *                                                 cannot be loaded) / RCCL or an error
@@ -338,6 +341,10 @@ void* rt_stream(rt_handle* h);
 int rt_test_device_units(rt_handle* h, int fn, const float* x, const float* y, float* out, uint64_t n);
 int rt_test_device_sample_texture(rt_handle* h, const rt_texture_desc* tex, const float* uv, float* rgba_out,
                                   uint64_t n);
+
+/* Test-only: raw copy of a buffer of the last wavefront sequence (which: 0 path state, 1 hit records, 2 the two slot
+ * lists, 3 the per-round list counts; layouts in csrc/rt_device.h). */
+int rt_test_read_wavefront(rt_handle* h, int which, void* out, uint64_t bytes);
 
 const char* rt_last_error(rt_handle* h);
 void rt_destroy(rt_handle* h);

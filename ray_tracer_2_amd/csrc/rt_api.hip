@@ -30,6 +30,9 @@ hipError_t launch_tile_order(const uint32_t* cost, uint32_t n_tiles, uint32_t ma
 hipError_t launch_primary(const RenderArgs& a, float* table, hipStream_t stream);
 hipError_t launch_blend_frames(const BlendArgs& b, hipStream_t stream);
 hipError_t launch_walk(const RenderArgs& a, uint32_t compute_units, hipStream_t stream);
+hipError_t launch_wf_shade(const RenderArgs& a, uint32_t blocks, hipStream_t stream);
+hipError_t launch_wf_walk(const RenderArgs& a, uint32_t blocks, hipStream_t stream);
+size_t wf_walk_lds_bytes(const RenderArgs& a);
 hipError_t launch_units(int fn, const float* x, const float* y, float* out, unsigned long long n, hipStream_t stream);
 hipError_t launch_units_texture(const uint8_t* rgba8, uint32_t width, uint32_t height, const float* srgb_lut, const float* uv,
                                 float* out, unsigned long long n, hipStream_t stream);
@@ -68,6 +71,16 @@ struct rt_handle {
     // longest chain of dependent segments, that only a big launch amortises) -- and off when the two park queues (224 B per pixel and frame of the
     // batch, each) would take more than a quarter of the free device memory
     int sort_rounds = -1;
+    // wavefront sequences (RenderArgs::wf_*): option "wavefront" 0 (default) = off, 1 = whenever legal (many-mesh scenes
+    // without a literal-stack mesh).  Off by default: measured slower than the inline kernels -- sponza-sized stand-in
+    // 10.65 -> 11.3 ms per frame, 200-mesh stand-in 5.0 -> 7.4 (tools/experiments/README.md)
+    int wavefront = 0;
+    bool any_deep = false;            // some mesh is walked with the shader's literal stack (not in the walk kernel)
+    float4* wf_state = nullptr;
+    float4* wf_hit = nullptr;
+    uint32_t* wf_lists = nullptr;     // two lists of wf_capacity slots
+    uint32_t* wf_counts = nullptr;
+    size_t wf_capacity = 0, wf_counts_capacity = 0;
     float4* park_queue[2] = {nullptr, nullptr};
     size_t park_capacity = 0;  // records per queue
     uint32_t* park_counts = nullptr;
@@ -382,6 +395,10 @@ void rt_destroy(rt_handle* h) {
     free_dev(h->park_queue[0]);
     free_dev(h->park_queue[1]);
     free_dev(h->park_counts);
+    free_dev(h->wf_state);
+    free_dev(h->wf_hit);
+    free_dev(h->wf_lists);
+    free_dev(h->wf_counts);
     if (h->multi_event) (void)hipEventDestroy(h->multi_event);
     if (h->multi_copied) (void)hipEventDestroy(h->multi_copied);
     if (g_rccl.lib)
@@ -858,6 +875,8 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->tlas_entries = tlas_entries;
         h->has_tlas = has_tlas;
         h->n_tlas_records = (uint32_t)tlas.size();
+        h->any_deep = false;
+        for (uint32_t i = 0; i < n_meshes; ++i) h->any_deep = h->any_deep || deep[i];
         h->has_forest = !forest_entries.empty();
         {
             bool plain = n_spheres == 0;
@@ -982,6 +1001,9 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "lds_top") {
         if (value < -1 || value > 2048) return fail(h, RT_ERR_INVALID_ARGUMENT, "lds_top must be -1 (auto), 0 (off) or a record count <= 2048");
         h->lds_top = value;
+    } else if (n == "wavefront") {
+        if (value < 0 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "wavefront must be 0 (off) or 1 (whenever legal)");
+        h->wavefront = value;
     } else if (n == "lds_tlas") {
         if (value < 0 || value > 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "lds_tlas must be 0 (off), 1 (when it costs no occupancy) or 2 (whenever it fits)");
         h->lds_tlas = value;
@@ -1215,6 +1237,69 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     }
     bool rounds = n_rounds > 0 && h->have_defer && a.many_mesh == 0 && a.kernel_variant == 0 && params->debug_flag == 0 &&
                   params->rays_per_pixel > 0;
+    // Wavefront sequence (RenderArgs::wf_*): many-mesh scenes whose meshes all walk with the ordinary stack.  One slot
+    // per pixel and frame of the launch (whole 8x8 tiles); a path makes at most rays_per_pixel x (bounces + 1)
+    // traversals, one per round.
+    const uint32_t wf_frame_slots = n_tiles * 64u;
+    const uint64_t wf_slots64 = (uint64_t)wf_frame_slots * (n_batch ? n_batch : 1u);
+    const uint64_t wf_rounds64 = params->number_of_bounces < 0 ? 0ull
+        : (uint64_t)(params->rays_per_pixel > 0 ? params->rays_per_pixel : 0) * ((uint64_t)params->number_of_bounces + 1ull);
+    bool wavefront = h->wavefront != 0 && a.many_mesh != 0 && !h->any_deep && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
+                     params->width <= 0xffffu && params->height <= 0xffffu && wf_slots64 < (1ull << 31) && wf_rounds64 <= 1024ull;
+    const size_t wf_bytes_per_slot = (WF_STATE_PLANES + WF_HIT_PLANES) * sizeof(float4) + 2 * sizeof(uint32_t) + PIXEL_MEMO_DWORDS * sizeof(uint32_t);
+    if (wavefront && h->wf_capacity < wf_slots64) {
+        size_t free_b = 0, total_b = 0;
+        const size_t want = (size_t)wf_slots64 * wf_bytes_per_slot;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || want > free_b / 2)
+            return fail(h, RT_ERR_OUT_OF_MEMORY, "wavefront: the path slots of this launch do not fit half of the free device memory");
+    }
+    if (wavefront) {
+        const size_t blocks64 = ((size_t)wf_slots64 + 63) / 64;
+        if (h->wf_capacity < wf_slots64) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            free_dev(h->wf_state);
+            free_dev(h->wf_hit);
+            free_dev(h->wf_lists);
+            h->wf_capacity = 0;
+            hipError_t e = hipMalloc((void**)&h->wf_state, blocks64 * WF_STATE_PLANES * 64 * sizeof(float4));
+            if (e == hipSuccess) e = hipMalloc((void**)&h->wf_hit, blocks64 * WF_HIT_PLANES * 64 * sizeof(float4));
+            if (e == hipSuccess) e = hipMalloc((void**)&h->wf_lists, 2 * blocks64 * 64 * sizeof(uint32_t));
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                free_dev(h->wf_state);
+                free_dev(h->wf_hit);
+                free_dev(h->wf_lists);
+                if (h->wavefront > 0) return fail(h, RT_ERR_OUT_OF_MEMORY, "wavefront: no device memory for the path slots");
+                wavefront = false;
+            } else {
+                h->wf_capacity = blocks64 * 64;
+                // (a hit record is only read after the walk kernel has written it; zeroed all the same, so that a slot
+                // the sequence mishandled would read as a miss instead of as indices into nowhere)
+                HIP_TRY(h, hipMemsetAsync(h->wf_state, 0, blocks64 * WF_STATE_PLANES * 64 * sizeof(float4), h->stream));
+                HIP_TRY(h, hipMemsetAsync(h->wf_hit, 0, blocks64 * WF_HIT_PLANES * 64 * sizeof(float4), h->stream));
+                HIP_TRY(h, hipMemsetAsync(h->wf_lists, 0, 2 * blocks64 * 64 * sizeof(uint32_t), h->stream));
+            }
+        }
+    }
+    if (wavefront) {
+        const size_t need_counts = (size_t)wf_rounds64 + 2;
+        if (h->wf_counts_capacity < need_counts) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            free_dev(h->wf_counts);
+            HIP_TRY(h, hipMalloc((void**)&h->wf_counts, need_counts * sizeof(uint32_t)));
+            h->wf_counts_capacity = need_counts;
+        }
+        // the slots' primary-ray memos: 13 dwords each, in blocks of 64 slots
+        const size_t need = (((size_t)wf_slots64 + 63) / 64) * 64 * PIXEL_MEMO_DWORDS;
+        if (h->pixel_cache_words < need) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            free_dev(h->pixel_cache_mem);
+            h->pixel_cache_words = 0;
+            HIP_TRY(h, hipMalloc((void**)&h->pixel_cache_mem, need * sizeof(uint32_t)));
+            h->pixel_cache_words = need;
+        }
+        rounds = false;
+    }
     if (rounds && h->park_capacity < park_records) {
         // the two park queues (an automatic sequence that cannot have them falls back to the plain launch)
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1291,7 +1376,53 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     }
     auto& ev = h->ev_pool[h->ev_used++];
     HIP_TRY(h, hipEventRecord(ev.first, h->stream));
-    if (!rounds) {
+    if (wavefront) {
+        // shade launch 0 takes the pixels; then, round after round, the walk kernel intersects the scene for the listed
+        // rays and the shade kernel finishes those segments and lists the next ones.  Everything is ordered on the
+        // stream; a launch whose list is empty ends at once.
+        const uint32_t R = (uint32_t)wf_rounds64;
+        HIP_TRY(h, hipMemsetAsync(h->wf_counts, 0, ((size_t)R + 2) * sizeof(uint32_t), h->stream));
+        RenderArgs w = a;
+        w.pixel_cache = h->pixel_cache_opt ? 3u : 0u;   // (0: no memo; every sample traverses)
+        w.pixel_cache_mem = h->pixel_cache_mem;
+        if (!w.pixel_cache) w.primary = nullptr;
+        w.tile_order = nullptr;
+        w.tile_cost = nullptr;
+        w.top_count = 0;
+        w.tlas_lds = 0;
+        w.wf_state = h->wf_state;
+        w.wf_hit = h->wf_hit;
+        w.wf_slots = (uint32_t)wf_slots64;
+        w.wf_frame_slots = wf_frame_slots;
+        uint32_t* lists[2] = {h->wf_lists, h->wf_lists + h->wf_capacity};
+        const uint32_t shade_blocks = h->compute_units * 4u;  // (the shade kernel is compiled for 4 waves per SIMD: 128 VGPRs)
+        const size_t wlds = wf_walk_lds_bytes(w);
+        uint32_t walk_per_cu = wlds ? (uint32_t)((160u * 1024u) / wlds) : BLOCKS_PER_CU;
+        if (walk_per_cu > BLOCKS_PER_CU) walk_per_cu = BLOCKS_PER_CU;
+        if (walk_per_cu < 1u) walk_per_cu = 1u;
+        const uint32_t walk_blocks = h->compute_units * walk_per_cu;
+        w.wf_round0 = 1;
+        w.wf_list_in = nullptr;
+        w.wf_count_in = nullptr;
+        w.wf_list_out = lists[0];
+        w.wf_count_out = h->wf_counts;
+        HIP_TRY(h, launch_wf_shade(w, shade_blocks, h->stream));
+        w.wf_round0 = 0;
+        for (uint32_t r = 0; r < R; ++r) {
+            w.wf_list_in = lists[r & 1u];
+            w.wf_count_in = h->wf_counts + r;
+            h->work_slot = (h->work_slot + 1) & 63u;
+            if (h->work_slot == 0u) HIP_TRY(h, hipMemsetAsync(h->work_counters, 0, 64 * sizeof(uint32_t), h->stream));
+            w.work_counter = h->work_counters + h->work_slot;
+            HIP_TRY(h, launch_wf_walk(w, walk_blocks, h->stream));
+            w.wf_list_out = lists[(r + 1) & 1u];
+            w.wf_count_out = h->wf_counts + r + 1;
+            HIP_TRY(h, launch_wf_shade(w, shade_blocks, h->stream));
+        }
+        h->last_launch[0] = (uint32_t)wlds;
+        h->last_launch[1] = walk_blocks;
+        h->last_launch[3] |= 16u;
+    } else if (!rounds) {
         HIP_TRY(h, launch_render(a, h->stream));
     } else {
         // launch 0 takes the tiles and parks every pixel in front of its first entry into the big mesh; then, round
@@ -1748,6 +1879,27 @@ int rt_test_device_sample_texture(rt_handle* h, const rt_texture_desc* tex, cons
     free_dev(dt);
     free_dev(duv);
     free_dev(dout);
+    return RT_OK;
+}
+
+// Test-only: raw copies of the wavefront sequence's buffers after the last launch (0 path state, 1 hit records,
+// 2 the two slot lists, 3 the per-round list counts), for tests/tools that check the sequence slot by slot.
+int rt_test_read_wavefront(rt_handle* h, int which, void* out, uint64_t bytes) {
+    if (!h || !out) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t blocks = h->wf_capacity / 64;
+    const void* src = nullptr;
+    size_t have = 0;
+    switch (which) {
+        case 0: src = h->wf_state; have = blocks * WF_STATE_PLANES * 64 * sizeof(float4); break;
+        case 1: src = h->wf_hit; have = blocks * WF_HIT_PLANES * 64 * sizeof(float4); break;
+        case 2: src = h->wf_lists; have = 2 * h->wf_capacity * sizeof(uint32_t); break;
+        case 3: src = h->wf_counts; have = h->wf_counts_capacity * sizeof(uint32_t); break;
+        default: return fail(h, RT_ERR_INVALID_ARGUMENT, "which must be 0..3");
+    }
+    if (!src || bytes > have) return fail(h, RT_ERR_INVALID_ARGUMENT, "no wavefront buffer of that size");
+    HIP_TRY(h, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -210,7 +210,31 @@ struct RenderArgs {
     float4* q_out;                // where this launch parks
     uint32_t* q_out_count;
     uint32_t defer_mesh, defer_xform;  // the deferred mesh and the mesh whose matrices give its local ray
+    // Wavefront sequence (option "wavefront"; many-mesh scenes).  Every ray of a many-mesh scene walks the top-level
+    // tree and a few meshes, the walks are of very unequal length, and inside the render kernel a wave-iteration lasts
+    // as long as its longest walk (lane utilisation 0.18 on the sponza-sized stand-in).  Here the path state of every
+    // pixel of the launch lives in a SLOT in global memory and two kernels alternate: rt_wf_shade_kernel finishes a
+    // segment (winner's normal / uv, shading, russian roulette, end of path / pixel) and begins the next one -- the
+    // operations of path_step around the traversal, unchanged -- and lists the slots whose new segment needs a
+    // traversal; rt_wf_walk_kernel intersects the scene for the listed rays with per-lane refill (a lane takes its
+    // next ray the moment its walk ends) and phase-scheduled passes (box steps / leaf triangles / bookkeeping, the
+    // most populated phase next).  A pixel's operations and their order are those of the undeferred loop.
+    //   wf_state: 6 float4 planes per slot, blocks of 64 slots: (x | out_row << 16, rng, j | fresh << 31, seg)
+    //             (ro, rd.x) (rd.yz, T.xy) (T.zw, light.xy) (light.zw, total.xy) (total.zw, meta, -)
+    //   wf_hit:   2 planes: (closest, object code | any << 24 | sphere inside << 25, win_u, win_v) (win_tri, win_point)
+    //             object code: mesh index, or 0x800000 | sphere index
+    //   the primary-ray memo of a slot: pixel_cache_mem, 13 dwords per slot (pixel_cache == 3)
+    float4* wf_state;
+    float4* wf_hit;
+    const uint32_t* wf_list_in;    // slots to shade (their hits are in wf_hit) / rays to walk
+    const uint32_t* wf_count_in;
+    uint32_t* wf_list_out;         // slots whose next segment needs a traversal
+    uint32_t* wf_count_out;
+    uint32_t wf_round0;            // 1 => the shade launch that takes the pixels: slots 0 .. wf_slots - 1, no hits yet
+    uint32_t wf_slots;             // slots of the launch = wf_frame_slots x frames
+    uint32_t wf_frame_slots;       // slots per frame = tiles x 64 (whole 8x8 tiles; pixels outside the image stay empty)
 };
+constexpr uint32_t WF_STATE_PLANES = 6, WF_HIT_PLANES = 2;
 // Park record of a pixel: 14 x 16 B, stored in blocks of 64 records, plane by plane (plane p of record i of block b at
 // float4 index (b * PARK_PLANES + p) * 64 + i), so that the lanes of a wave, which hold consecutive records, store and
 // load contiguous kilobytes.  Planes: 0 (x, out_row, rng, j)  1 (seg, fresh, meta, memo[12])  2 (ro, rd.x)

@@ -148,7 +148,7 @@ class RayTracer:
         self._check(self._L.rt_last_launch(self._h, C.byref(out)))
         return {"lds_bytes_per_workgroup": out[0], "workgroups": out[1], "scene_in_lds": bool(out[2]),
                 "many_mesh": bool(out[3] & 1), "specialised": bool(out[3] & 2), "one_wave_per_tile": bool(out[3] & 4),
-                "deferred_walks": bool(out[3] & 8)}
+                "deferred_walks": bool(out[3] & 8), "wavefront": bool(out[3] & 16)}
 
     @property
     def device_image_ptr(self):

@@ -778,3 +778,77 @@ def test_library_scenes_on_reference_data(rt, oracle, tracer, name):
         assert same(gpu, ref) and s.segments == st.segments
     if name == "texture_test":
         assert np.unique(bits(gpu[..., :3])).size > 20000   # (the textured earth, not a flat colour)
+
+
+def _wavefront_check(rt, oracle, tracer, arrays, w, h, bounces, spp, frames0=0, n_frames=1, counters=True, strips=None):
+    """Renders with option wavefront = 1 (forced) and compares image, ray count and (counter kernels) the node / triangle
+    test counters with the oracle's over the same frames."""
+    ref = np.zeros((h, w, 4), np.float32)
+    seg = nt = tt = 0
+    for f in range(frames0, frames0 + n_frames):
+        ref, st = oracle.render(rt.make_params(w, h, bounces, spp, skybox=1, frames=f), arrays, image=ref)
+        seg, nt, tt = seg + st.segments, nt + st.node_tests, tt + st.triangle_tests
+    p = rt.make_params(w, h, bounces, spp, skybox=1, frames=frames0)
+    for c in ((True, False) if counters else (False,)):
+        tracer.set_counters(c)
+        tracer.write_image(np.zeros((h, w, 4), np.float32))
+        tracer.reset_timing()
+        if n_frames == 1:
+            tracer.render(p)
+        else:
+            tracer.render_frames(p, n_frames)
+        got, s = tracer.read_image(w, h), tracer.stats()
+        assert tracer.last_launch()["wavefront"], "the wavefront sequence did not run"
+        assert same(got, ref), (w, h, bounces, spp, frames0, n_frames, c)
+        assert s.segments == seg
+        if c:
+            assert (s.node_tests, s.triangle_tests) == (nt, tt)
+    tracer.set_counters(False)
+    return ref
+
+
+def test_wavefront_sequences_do_not_change_the_bits(rt, oracle, tracer):
+    """Option wavefront (RenderArgs::wf_*): path state in memory slots, rt_wf_shade_kernel and rt_wf_walk_kernel
+    alternating -- on the many-mesh scenes (top-level trees, single meshes with root-box culling, root-leaf meshes,
+    spheres, glass, textures, depth of field), image, ray count and test counters are those of the inline kernels and
+    of the oracle: single frames, accumulated batches, frames = -1, no bounces, one sample, strips, no memo."""
+    from ray_tracer_2_amd import scenes
+    a200 = rt.SceneArrays.from_scene(scenes.sponza_standin(200))
+    try:
+        tracer.set_option("wavefront", 1)
+        tracer.load_scene(a200)
+        _wavefront_check(rt, oracle, tracer, a200, 192, 108, 4, 4)
+        _wavefront_check(rt, oracle, tracer, a200, 100, 52, 3, 2, frames0=0, n_frames=5)        # a batch, ragged tiles
+        _wavefront_check(rt, oracle, tracer, a200, 96, 54, 3, 2, frames0=-1, counters=False)
+        _wavefront_check(rt, oracle, tracer, a200, 96, 54, 0, 3, counters=False)                 # no bounces
+        _wavefront_check(rt, oracle, tracer, a200, 96, 54, -1, 2, counters=False)                # no segments at all
+        _wavefront_check(rt, oracle, tracer, a200, 96, 54, 5, 1, frames0=3, counters=False)      # blends in place
+        tracer.set_option("pixel_cache", 0)
+        _wavefront_check(rt, oracle, tracer, a200, 96, 54, 3, 3, counters=False)
+        tracer.set_option("pixel_cache", 1)
+        # strips: every rank of 3, against the inline kernels
+        w, h = 120, 70
+        p = rt.make_params(w, h, 3, 2, skybox=1, frames=0)
+        for rank in range(3):
+            outs = []
+            for wf in (0, 1):
+                tracer.set_option("wavefront", wf)
+                tracer.write_image(np.zeros((h, w, 4), np.float32))
+                tracer.render_strips_frames(p, 3, rank, 3)
+                outs.append(tracer.read_image(w, h).copy())
+            assert same(outs[0], outs[1]), rank
+        tracer.set_option("wavefront", 1)
+        # the scene read from global memory
+        a340 = rt.SceneArrays.from_scene(scenes.sponza_standin(340, detail=8))
+        tracer.load_scene(a340)
+        _wavefront_check(rt, oracle, tracer, a340, 160, 90, 4, 2)
+        _wavefront_check(rt, oracle, tracer, a340, 128, 72, 3, 2, n_frames=3, counters=False)
+        # random many-mesh scenes: several transform groups with trees of random shape, glass, spheres, depth of field
+        for seed in (101, 102, 103, 104, 105, 106):
+            ar = _random_scene(rt, seed, many=True)
+            tracer.load_scene(ar)
+            _wavefront_check(rt, oracle, tracer, ar, 80, 45, 4, 3, n_frames=2 if seed % 2 else 1)
+    finally:
+        tracer.set_counters(False)
+        tracer.set_option("wavefront", 0)
+        tracer.set_option("pixel_cache", 1)
