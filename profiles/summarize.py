@@ -105,6 +105,8 @@ def main():
     # the render kernel = the rt_render instantiation launched most often (tools/bench_scene.py also runs ONE frame of
     # the counter-keeping instantiation at the end: not part of the averages)
     names = collections.Counter(r["Kernel_Name"] for r in trace if "rt_render" in r["Kernel_Name"])
+    if not names:   # a wavefront sequence: its walk kernel is the one to describe
+        names = collections.Counter(r["Kernel_Name"] for r in trace if "rt_wf_walk" in r["Kernel_Name"])
     render_name = names.most_common(1)[0][0] if names else "rt_render"
     tr = [r for r in trace if r["Kernel_Name"] == render_name]
     bl = [r for r in trace if "rt_blend" in r["Kernel_Name"]]
@@ -194,9 +196,11 @@ def main():
             rate = agg["SQ_INSTS_VALU"] / dur(steady) / 1e9
             lines.append(f"VALU issue: {rate:.0f} G wave-instructions/s = {rate / (simds * clk / 2):.2f} of the guide's peak "
                          f"(one wave64 instruction per 2 cycles per SIMD x {simds} SIMDs x {clk:.2f} GHz = {simds * clk / 2:.0f} G/s)")
+    whole_run_hbm = None
     if args.total_frames:
         F = args.total_frames
-        fam = lambda name: "walk" if "rt_walk" in name else "blend" if "rt_blend" in name else "render" if "rt_render" in name else None
+        fam = lambda name: ("walk" if "rt_walk" in name or "rt_wf_walk" in name else "shade" if "rt_wf_shade" in name else
+                            "blend" if "rt_blend" in name else "render" if "rt_render" in name else None)
         lines.append("")
         lines.append(f"== whole run: sums over all render / walk / blend launches, per frame ({F} frames incl. warm-up) ==")
         tsum = collections.Counter()
@@ -207,7 +211,7 @@ def main():
                 tsum[f] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
                 nl[f] += 1
         tot_t = sum(tsum.values())
-        lines.append("kernel time per frame: " + ", ".join(f"{k} {tsum[k] / F * 1e3:.3f} ms ({nl[k]} launches)" for k in ("render", "walk", "blend") if nl[k])
+        lines.append("kernel time per frame: " + ", ".join(f"{k} {tsum[k] / F * 1e3:.3f} ms ({nl[k]} launches)" for k in ("render", "shade", "walk", "blend") if nl[k])
                      + f" = {tot_t / F * 1e3:.3f} ms")
         csum = collections.defaultdict(collections.Counter)
         for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_l2"):
@@ -218,15 +222,20 @@ def main():
         tc = lambda k: sum(csum[k].values())
         if "FETCH_SIZE" in csum and "WRITE_SIZE" in csum:
             hb = tc("FETCH_SIZE") * 2048 + tc("WRITE_SIZE") * 1024
+            whole_run_hbm = hb / F
             lines.append(f"HBM traffic per frame: read {tc('FETCH_SIZE') * 2048 / F / 1e6:.1f} MB + write {tc('WRITE_SIZE') * 1024 / F / 1e6:.1f} MB = {hb / F / 1e6:.1f} MB "
                          f"(walk kernels: {(csum['FETCH_SIZE']['walk'] * 2048 + csum['WRITE_SIZE']['walk'] * 1024) / F / 1e6:.1f} MB) = "
                          f"{hb / tot_t / 1e9:.0f} GB/s = {hb / tot_t / 8e12:.3f} of the 8 TB/s peak")
         if "SQ_INSTS_VALU" in csum:
-            lines.append(f"VALU instructions per frame: {tc('SQ_INSTS_VALU') / F:.4g} (render {csum['SQ_INSTS_VALU']['render'] / F:.4g}, walk {csum['SQ_INSTS_VALU']['walk'] / F:.4g})")
+            lines.append(f"VALU instructions per frame: {tc('SQ_INSTS_VALU') / F:.4g} (" + ", ".join(f"{k} {csum['SQ_INSTS_VALU'][k] / F:.4g}" for k in ("render", "shade", "walk") if csum['SQ_INSTS_VALU'][k]) + ")")
         if "SQ_THREAD_CYCLES_VALU" in csum and "SQ_ACTIVE_INST_VALU" in csum:
             lu = lambda f: csum["SQ_THREAD_CYCLES_VALU"][f] / max(64 * csum["SQ_ACTIVE_INST_VALU"][f], 1)
-            lines.append(f"VALU lane utilisation: render kernels {lu('render'):.3f}, walk kernels {lu('walk'):.3f}, all "
-                         f"{tc('SQ_THREAD_CYCLES_VALU') / (64 * tc('SQ_ACTIVE_INST_VALU')):.3f}")
+            lines.append("VALU lane utilisation: " + ", ".join(f"{k} kernels {lu(k):.3f}" for k in ("render", "shade", "walk") if csum["SQ_ACTIVE_INST_VALU"][k])
+                         + f", all {tc('SQ_THREAD_CYCLES_VALU') / (64 * tc('SQ_ACTIVE_INST_VALU')):.3f}")
+        if "SQ_WAIT_ANY" in csum and "SQ_WAVE_CYCLES" in csum:
+            lines.append("wave time in s_waitcnt: " + ", ".join(f"{k} kernels {csum['SQ_WAIT_ANY'][k] / max(csum['SQ_WAVE_CYCLES'][k], 1):.1%}"
+                                                                for k in ("render", "shade", "walk") if csum["SQ_WAVE_CYCLES"][k])
+                         + f", all {tc('SQ_WAIT_ANY') / max(tc('SQ_WAVE_CYCLES'), 1):.1%}")
         if "TCC_HIT_sum" in csum:
             lines.append(f"L2 hit rate {tc('TCC_HIT_sum') / (tc('TCC_HIT_sum') + tc('TCC_MISS_sum')):.1%}")
     if args.demand_json and os.path.exists(args.demand_json):
@@ -241,6 +250,8 @@ def main():
                          f"{dj['demand_bytes_per_frame'] / 1e9:.2f} GB per frame")
             if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
                 per_frame = (agg["FETCH_SIZE"] * 2048 + agg["WRITE_SIZE"] * 1024 + agg_blend.get("FETCH_SIZE", 0) * 2048 + agg_blend.get("WRITE_SIZE", 0) * 1024) / args.frames_per_launch
+                if args.total_frames and whole_run_hbm is not None:
+                    per_frame = whole_run_hbm   # a sequence of launches per batch: the sums over ALL launches, per frame
                 lines.append(f"counter bytes (HBM): {per_frame / 1e6:.1f} MB per frame = {per_frame / dj['demand_bytes_per_frame']:.4f} of the demand bytes "
                              f"(the rest is served by LDS / L1 / L2); compulsory = image {dj['width'] * dj['height'] * 32 / 1e6:.1f} MB + scene once "
                              f"{dj.get('scene_bytes_reference_layout', 0) / 1e6:.1f} MB")
