@@ -317,6 +317,8 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 for that many rounds; -1: by the work of the launch and the mesh's size,
  *                                                 and only while both park queues fit a quarter of the free memory
  *   defer_min_nodes       >= 1 (1024) (upload)    smallest BVH (internal nodes) whose mesh may be the deferred one
+ *   hybrid                0 / 1 (0)               the parking launches of a deferred-walk sequence stage everything but the big
+ *                                                 mesh into LDS (measured no faster: DESIGN.md section 5.4)
  *   wavefront             0 / 1 (0)               wavefront sequences (many-mesh scenes): path state in memory slots, a shading
  *                                                 kernel and a ray-walk kernel with per-lane refill alternate (measured slower
  *                                                 than the inline kernels: DESIGN.md section 5.5)

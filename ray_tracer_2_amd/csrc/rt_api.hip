@@ -81,6 +81,15 @@ struct rt_handle {
     uint32_t* wf_lists = nullptr;     // two lists of wf_capacity slots
     uint32_t* wf_counts = nullptr;
     size_t wf_capacity = 0, wf_counts_capacity = 0;
+    // Hybrid launches of a deferred-walk sequence (option "hybrid"): everything but the deferred mesh's BVH and triangles
+    // -- mesh records, materials, items, the small meshes' records and triangles -- as a blob of its own that the
+    // parking render launches stage into LDS (they never walk the big mesh); only a winner on the big mesh reads its
+    // shading record from the full blob.
+    float4* small_blob = nullptr;
+    SceneLayout small_lay{};
+    uint32_t small_stack_entries = 1;
+    bool small_ok = false;
+    int hybrid = 0;  // option "hybrid" (default 0: measured no faster -- config 3 stand-in 6.04 -> 6.11 ms, config 5 geometry 3.49 -> 3.48)
     float4* park_queue[2] = {nullptr, nullptr};
     size_t park_capacity = 0;  // records per queue
     uint32_t* park_counts = nullptr;
@@ -203,6 +212,8 @@ void free_dev(T*& p) {
 
 void free_scene(rt_handle* h) {
     free_dev(h->blob);
+    free_dev(h->small_blob);
+    h->small_ok = false;
     h->have_scene = false;
 }
 
@@ -441,6 +452,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         std::vector<WideRec> wide;
         std::vector<uint32_t> wide_base(n_meshes), root_idx(n_meshes), root_count(n_meshes);
         std::vector<char> deep(n_meshes, 0);
+        std::vector<uint32_t> tri_lo(n_meshes, 0xffffffffu), tri_hi(n_meshes, 0u), mesh_need(n_meshes, 0u);  // triangle range, stack entries
         std::vector<uint32_t> wide_index(n_nodes, 0xffffffffu);  // per original node
         uint32_t max_height = 0, max_leaf_ref = 0;  // (largest triangle count of a leaf that can go on a stack)
         uint32_t top_mesh_records = 0, top_mesh_base = 0;
@@ -458,6 +470,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             deep[i] = height + 1 > RT_BVH_STACK;
             const uint32_t need = deep[i] ? RT_BVH_STACK : height;
             if (need > max_height) max_height = need;
+            mesh_need[i] = need;
             // Wide records: internal nodes in DFS pre-order, indexed per mesh.
             // (Meshes may alias node ranges; records are built per mesh.)
             wide_base[i] = (uint32_t)wide.size();
@@ -467,6 +480,8 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             if (mn[0].count > 0) {
                 root_idx[i] = m.triangle_offset + mn[0].first;
                 root_count[i] = mn[0].count;
+                tri_lo[i] = root_idx[i];
+                tri_hi[i] = root_idx[i] + root_count[i];
                 continue;
             }
             root_idx[i] = wide_base[i];
@@ -505,6 +520,8 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                         idx = m.triangle_offset + c.first;
                         cnt = c.count;
                         if (cnt > max_leaf_ref) max_leaf_ref = cnt;
+                        tri_lo[i] = std::min(tri_lo[i], idx);
+                        tri_hi[i] = std::max(tri_hi[i], idx + cnt);
                     } else {
                         idx = wide_base[i] + wide_index[m.node_offset + local];
                         cnt = 0;
@@ -769,15 +786,18 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         // ---- blob layout ------------------------------------------------------
         SceneLayout lay{};
         uint64_t off = 0;
+        // (the per-scene sections first, the per-node / per-triangle arrays last: the small blob of the hybrid launches has
+        // the same sections with shorter arrays, so every offset up to wide_off is the same in both -- the primary-ray memo
+        // keeps a material's byte offset across launches that read different blobs)
         lay.mesh_off = (uint32_t)off;   off += (uint64_t)n_meshes * MESH_REC_BYTES;
-        lay.wide_off = (uint32_t)off;   off += (uint64_t)wide.size() * WIDE_REC_BYTES;
-        lay.tri_off = (uint32_t)off;    off += (uint64_t)n_triangles * TRI_ISECT_BYTES;
-        lay.shade_off = (uint32_t)off;  off += (uint64_t)n_triangles * TRI_SHADE_BYTES;
         lay.mat_off = (uint32_t)off;    off += (uint64_t)(n_meshes + n_spheres) * MATERIAL_BYTES;
         lay.sphere_off = (uint32_t)off; off += (uint64_t)n_spheres * SPHERE_BYTES;
         lay.item_off = (uint32_t)off;   off += (uint64_t)items.size() * ITEM_BYTES;
         lay.tlas_off = (uint32_t)off;   off += (uint64_t)tlas.size() * WIDE_REC_BYTES;
         lay.forest_off = (uint32_t)off; off += (uint64_t)forest_entries.size() * FOREST_ENTRY_BYTES;
+        lay.wide_off = (uint32_t)off;   off += (uint64_t)wide.size() * WIDE_REC_BYTES;
+        lay.tri_off = (uint32_t)off;    off += (uint64_t)n_triangles * TRI_ISECT_BYTES;
+        lay.shade_off = (uint32_t)off;  off += (uint64_t)n_triangles * TRI_SHADE_BYTES;
         if (off == 0) off = 16;
         if (off > 0xfffffff0ull) return fail(h, RT_ERR_CAPACITY, "scene larger than 4 GiB");
         lay.bytes = (uint32_t)off;
@@ -837,6 +857,56 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         free_scene(h);
         int rc;
         if ((rc = upload(h, h->blob, blob.data(), blob.size())) != RT_OK) return rc;
+        // ---- the small blob of the hybrid launches: the scene without the deferred mesh's BVH and triangles ----
+        // Possible when that mesh's wide records and triangles are the LAST of their arrays (indices are absolute:
+        // the other meshes' then form a prefix) -- true of scenes that add one big model to a small set.
+        std::vector<float4> small;
+        SceneLayout sl{};
+        uint32_t small_need = 1;
+        bool small_ok = false;
+        if (have_defer) {
+            const uint32_t d = defer_mesh;
+            bool last = wide_base[d] + defer_internal == (uint32_t)wide.size();
+            for (uint32_t i = 0; i < n_meshes; ++i)
+                if (i != d) {
+                    if (tri_hi[i] > tri_lo[d] || wide_base[i] > wide_base[d]) last = false;
+                    small_need = std::max(small_need, mesh_need[i]);
+                }
+            if (last && tri_lo[d] <= n_triangles) {
+                const uint32_t nw = wide_base[d], nt = tri_lo[d];
+                uint64_t o = 0;
+                sl.mesh_off = (uint32_t)o;   o += (uint64_t)n_meshes * MESH_REC_BYTES;
+                sl.mat_off = (uint32_t)o;    o += (uint64_t)(n_meshes + n_spheres) * MATERIAL_BYTES;
+                sl.sphere_off = (uint32_t)o; o += (uint64_t)n_spheres * SPHERE_BYTES;
+                sl.item_off = (uint32_t)o;   o += (uint64_t)items.size() * ITEM_BYTES;
+                sl.tlas_off = (uint32_t)o;   o += (uint64_t)tlas.size() * WIDE_REC_BYTES;
+                sl.forest_off = (uint32_t)o; o += (uint64_t)forest_entries.size() * FOREST_ENTRY_BYTES;
+                sl.wide_off = (uint32_t)o;   o += (uint64_t)nw * WIDE_REC_BYTES;
+                sl.tri_off = (uint32_t)o;    o += (uint64_t)nt * TRI_ISECT_BYTES;
+                sl.shade_off = (uint32_t)o;  o += (uint64_t)nt * TRI_SHADE_BYTES;
+                sl.bytes = (uint32_t)o;
+                if (sl.mat_off != lay.mat_off || sl.wide_off != lay.wide_off) o = (uint64_t)LDS_BUDGET_BYTES + 1;  // (cannot happen: same leading sections)
+                if (o <= LDS_BUDGET_BYTES) {
+                    small.assign(o / 16, make_float4(0, 0, 0, 0));
+                    auto copy = [&](uint32_t dst, uint32_t src, uint64_t bytes) {
+                        if (bytes) memcpy(small.data() + dst / 16, blob.data() + src / 16, bytes);
+                    };
+                    copy(sl.mesh_off, lay.mesh_off, (uint64_t)n_meshes * MESH_REC_BYTES);
+                    copy(sl.wide_off, lay.wide_off, (uint64_t)nw * WIDE_REC_BYTES);
+                    copy(sl.tri_off, lay.tri_off, (uint64_t)nt * TRI_ISECT_BYTES);
+                    copy(sl.shade_off, lay.shade_off, (uint64_t)nt * TRI_SHADE_BYTES);
+                    copy(sl.mat_off, lay.mat_off, (uint64_t)(n_meshes + n_spheres) * MATERIAL_BYTES);
+                    copy(sl.sphere_off, lay.sphere_off, (uint64_t)n_spheres * SPHERE_BYTES);
+                    copy(sl.item_off, lay.item_off, (uint64_t)items.size() * ITEM_BYTES);
+                    copy(sl.forest_off, lay.forest_off, (uint64_t)forest_entries.size() * FOREST_ENTRY_BYTES);
+                    small_ok = true;
+                }
+            }
+        }
+        if (small_ok && (rc = upload(h, h->small_blob, small.data(), small.size())) != RT_OK) return rc;
+        h->small_ok = small_ok;
+        h->small_lay = sl;
+        h->small_stack_entries = small_need;
         HIP_TRY(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
         // The root-box shortcut needs root box == union of the two child boxes, bit for bit
         // (true for the reference's builder; verified, not assumed, since BVHs may be foreign).
@@ -1004,6 +1074,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "wavefront") {
         if (value < 0 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "wavefront must be 0 (off) or 1 (whenever legal)");
         h->wavefront = value;
+    } else if (n == "hybrid") {
+        h->hybrid = value ? 1 : 0;
     } else if (n == "lds_tlas") {
         if (value < 0 || value > 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "lds_tlas must be 0 (off), 1 (when it costs no occupancy) or 2 (whenever it fits)");
         h->lds_tlas = value;
@@ -1448,7 +1520,38 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         a.q_in_count = nullptr;
         a.q_out = h->park_queue[0];
         a.q_out_count = h->park_counts;
-        HIP_TRY(h, launch_render(a, h->stream));
+        // Hybrid launches: the render launches that PARK never walk the big mesh, so they run the LDS-scene kernels on
+        // the small blob (everything but the big mesh's BVH and triangles) with the small meshes' stack depth; a winner on
+        // the big mesh reads its shading record from the full blob.  The last launch (park = 0) and rt_walk_kernel
+        // read the full blob as before.
+        RenderArgs ah = a;
+        bool hybrid = h->hybrid != 0 && h->small_ok && !a.lds_scene && a.count_tests == 0 && a.kernel_variant == 0;
+        if (hybrid) {
+            ah.blob = h->small_blob;
+            ah.lay = h->small_lay;
+            ah.lds_scene = 1;
+            ah.hybrid = 1;
+            ah.big_blob = h->blob;
+            ah.big_shade_off = h->lay.shade_off;
+            ah.top_count = 0;
+            ah.stack_entries = h->small_stack_entries ? h->small_stack_entries : 1u;
+            ah.stack_wide = 0;
+            ah.pixel_cache = h->pixel_cache_opt ? 1u : 0u;
+            if (ah.pixel_cache && render_lds_bytes(ah) > LDS_BUDGET_BYTES) {
+                ah.pixel_cache = a.pixel_cache == 2u ? 2u : 0u;   // (the global-memory memo the plain launches use, if they have one)
+                ah.pixel_cache_mem = a.pixel_cache_mem;
+            }
+            if (!ah.pixel_cache) ah.primary = nullptr;
+            if (render_lds_bytes(ah) > LDS_BUDGET_BYTES) hybrid = false;
+            ah.persistent_blocks = h->persistent_blocks;
+        }
+        if (!hybrid) ah = a;
+        auto sync_queues = [&]() {  // (the queue fields move with the rounds: keep the hybrid copy's in step)
+            ah.park = a.park; ah.q_in = a.q_in; ah.q_in_count = a.q_in_count; ah.q_out = a.q_out; ah.q_out_count = a.q_out_count;
+            ah.work_counter = a.work_counter; ah.defer_mesh = a.defer_mesh; ah.defer_xform = a.defer_xform;
+        };
+        sync_queues();
+        HIP_TRY(h, launch_render(ah, h->stream));
         for (uint32_t r = 0; r < R; ++r) {
             const bool last = r + 1 == R;
             a.q_in = h->park_queue[r & 1u];
@@ -1463,7 +1566,8 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             a.park = last ? 0u : 1u;
             a.q_out = last ? nullptr : h->park_queue[(r + 1) & 1u];
             a.q_out_count = last ? nullptr : h->park_counts + r + 1;
-            HIP_TRY(h, launch_render(a, h->stream));
+            sync_queues();
+            HIP_TRY(h, launch_render(last ? a : ah, h->stream));
         }
     }
     if (n_batch) {

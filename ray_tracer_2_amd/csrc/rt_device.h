@@ -210,6 +210,12 @@ struct RenderArgs {
     float4* q_out;                // where this launch parks
     uint32_t* q_out_count;
     uint32_t defer_mesh, defer_xform;  // the deferred mesh and the mesh whose matrices give its local ray
+    // Hybrid launch of a deferred-walk sequence (option "hybrid"): `blob` / `lay` are the SMALL blob -- the scene without
+    // the deferred mesh's BVH and triangles, staged into LDS -- and only a winner on the deferred mesh reads its shading
+    // record from the full blob in global memory.
+    uint32_t hybrid;
+    uint32_t big_shade_off;
+    const float4* big_blob;
     // Wavefront sequence (option "wavefront"; many-mesh scenes).  Every ray of a many-mesh scene walks the top-level
     // tree and a few meshes, the walks are of very unequal length, and inside the render kernel a wave-iteration lasts
     // as long as its longest walk (lane utilisation 0.18 on the sponza-sized stand-in).  Here the path state of every

@@ -674,7 +674,9 @@ DEV void isect_spheres(const RenderArgs& a, f3 ro, f3 rd, Isect& I) {
 
 // Per-object outputs that only the overall winner needs (normals, uv) are computed once after
 // the loops from the same inputs, which yields the same bits.
-template <bool LDS, bool SIMPLE = false>
+// HYB (hybrid launches of a deferred-walk sequence, RenderArgs::hybrid): the staged blob lacks the deferred mesh's
+// triangles; a winner on that mesh reads its shading record from the full blob.
+template <bool LDS, bool SIMPLE = false, bool HYB = false>
 DEV Hit isect_finish(const RenderArgs& a, const Isect& I, f3 ro, f3 rd) {
     Hit h;
     h.hit = I.any;
@@ -693,8 +695,13 @@ DEV Hit isect_finish(const RenderArgs& a, const Isect& I, f3 ro, f3 rd) {
             const uint32_t so = a.lay.shade_off + (I.win_tri & 0x7fffffffu) * TRI_SHADE_BYTES;
             const bool det_negative = (I.win_tri & 0x80000000u) != 0u;
             const float wu = I.win_u, wv = I.win_v, ww = (1.0f - wu) - wv;
-            const float4 s0 = ld4<LDS>(a, so), s1 = ld4<LDS>(a, so + 16), s2 = ld4<LDS>(a, so + 32),
-                         s3 = ld4<LDS>(a, so + 48);
+            float4 s0, s1, s2, s3;
+            if (HYB && (uint32_t)I.object == a.defer_mesh) {
+                const float4* g = a.big_blob + ((a.big_shade_off + (I.win_tri & 0x7fffffffu) * TRI_SHADE_BYTES) >> 4);
+                s0 = g[0]; s1 = g[1]; s2 = g[2]; s3 = g[3];
+            } else {
+                s0 = ld4<LDS>(a, so); s1 = ld4<LDS>(a, so + 16); s2 = ld4<LDS>(a, so + 32); s3 = ld4<LDS>(a, so + 48);
+            }
             f3 n1{s0.x, s0.y, s0.z}, n2{s1.x, s1.y, s1.z}, n3{s2.x, s2.y, s2.z};
             f3 ln = normalize3((n1 * ww + n2 * wu) + n3 * wv) * (det_negative ? -1.0f : 1.0f);
             const float4 c0 = ld4<LDS>(a, mo + 64), c1 = ld4<LDS>(a, mo + 80), c2 = ld4<LDS>(a, mo + 96),
@@ -731,7 +738,7 @@ DEV Hit isect_finish(const RenderArgs& a, const Isect& I, f3 ro, f3 rd) {
 // jitter (RenderArgs::simple, decided by the host per launch) -- the instantiation BASELINE configs 2, 3 and 5 run.
 // The general code is the same code with those branches present; compiled out, they stop costing registers at the
 // kernels' 96-VGPR ceiling and instruction-cache space.
-template <bool LDS, bool STATS, bool TLAS, bool PARK = false, bool SIMPLE = false>
+template <bool LDS, bool STATS, bool TLAS, bool PARK = false, bool SIMPLE = false, bool HYB = false>
 DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int& node_tests,
                         int& tri_tests, Isect& I_parked) {
     // this lane's TLAS stack column sits behind the wave's BVH stack columns
@@ -1027,7 +1034,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
         h.suspended = true;
         return h;
     }
-    return isect_finish<LDS, SIMPLE>(a, I, ro, rd);
+    return isect_finish<LDS, SIMPLE, HYB>(a, I, ro, rd);
 }
 
 // field byte offsets inside rt_material
@@ -1563,7 +1570,7 @@ template <bool TOTAL_LDS>
 DEV void park_store(const RenderArgs& a, uint32_t slot, const PixelState& s, uint32_t* ls, const Isect& I);
 DEV void park_load_hit(const RenderArgs& a, uint32_t slot, Isect& I, CompactHit& walked);
 
-template <bool LDS, bool STATS, bool TLAS, bool PARK = false, bool SIMPLE = false>
+template <bool LDS, bool STATS, bool TLAS, bool PARK = false, bool SIMPLE = false, bool HYB = false>
 DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
                        bool& reused, int& node_tests, int& tri_tests, uint32_t resume_slot = 0xffffffffu) {
     // (a resumed pixel was parked behind path_begin: its segment has begun)
@@ -1581,7 +1588,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
     } else if (mode == STEP_TRAVERSE) {
         TIC(t0);
         Isect I;
-        hit = intersect_scene<LDS, STATS, TLAS, PARK, SIMPLE>(a, s.ro, s.rd, stack_of<total_in_lds(LDS)>(ls), node_tests, tri_tests, I);
+        hit = intersect_scene<LDS, STATS, TLAS, PARK, SIMPLE, HYB>(a, s.ro, s.rd, stack_of<total_in_lds(LDS)>(ls), node_tests, tri_tests, I);
         TOC(t0, 0);
         if constexpr (PARK && !TLAS) {
             if (a.park != 0u) {  // (wave-uniform)
@@ -1617,7 +1624,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
             world_hit<LDS>(a, a.lay.mesh_off + a.defer_mesh * MESH_REC_BYTES + 64u, lo, ld, s.ro, walked.t, whp, wdst);
             isect_offer(I, a.defer_mesh, walked, whp, wdst);
         }
-        hit = isect_finish<LDS, SIMPLE>(a, I, s.ro, s.rd);
+        hit = isect_finish<LDS, SIMPLE, HYB>(a, I, s.ro, s.rd);
         memo_hit_store<STATS>(a, s, ls, hit);
     }
     return path_end<LDS, total_in_lds(LDS), SIMPLE>(a, s, ls, mode, hit, n_segments) ? PATH_PIXEL_DONE : PATH_CONTINUE;
@@ -1792,7 +1799,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
 // wave's current tile, so the wave stays full until the frame runs out.  The
 // per-pixel RNG stream depends only on the pixel's coordinates, so the image
 // does not depend on which lane rendered which pixel.
-template <bool LDS, bool STATS, bool TLAS, bool PARK, bool SIMPLE>
+template <bool LDS, bool STATS, bool TLAS, bool PARK, bool SIMPLE, bool HYB = false>
 __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persistent_kernel(const RenderArgs a) {
 #if defined(RT_DIAG) || defined(RT_WAVE_TIMES)
     const unsigned long long t_wave_start = __builtin_amdgcn_s_memrealtime();
@@ -1906,7 +1913,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         uint32_t step = PATH_CONTINUE;
         bool reused = false;
         if (active) {
-            step = path_step<LDS, STATS, TLAS, PARK, SIMPLE>(a, s, ls, starve, n_segments, reused, node_tests, tri_tests, resume_slot);
+            step = path_step<LDS, STATS, TLAS, PARK, SIMPLE, HYB>(a, s, ls, starve, n_segments, reused, node_tests, tri_tests, resume_slot);
             resume_slot = 0xffffffffu;
             if (step == PATH_PIXEL_DONE) {
                 DIAG(16);
@@ -2741,7 +2748,10 @@ static void launch_variant(const RenderArgs& a, uint32_t ntiles, size_t lds, hip
         if (blocks == 0) blocks = 1;
         const bool park = !TLAS && (a.park != 0u || a.q_in != nullptr);  // a launch of a deferred-walk sequence
         if (park) {
-            if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS, !TLAS, false>, blocks, lds, stream, a);
+            if (LDS && !TLAS && a.hybrid != 0u && a.count_tests == 0u) {  // (host: only launches that park)
+                if (simple) launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS, !TLAS, LDS && !TLAS>, blocks, lds, stream, a);
+                else launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS, false, LDS && !TLAS>, blocks, lds, stream, a);
+            } else if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS, !TLAS, false>, blocks, lds, stream, a);
             else if (simple) launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS, !TLAS>, blocks, lds, stream, a);
             else launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS, false>, blocks, lds, stream, a);
         } else {

@@ -477,6 +477,18 @@ def test_deferred_walks_do_not_change_the_bits(rt, oracle, tracer, dragon_arrays
                 tracer.render_frames(p, 3)
                 assert same(tracer.read_image(W, H), acc), (counters, rounds, "batch")
         tracer.set_counters(False)
+        # option hybrid = 1: the parking launches stage everything but the big mesh into LDS (and only a winner on the big
+        # mesh reads its shading record from global memory) instead of reading the whole scene in place -- the same bits
+        tracer.set_option("hybrid", 1)
+        for rounds in (2, 5):
+            tracer.set_option("sort_rounds", rounds)
+            tracer.write_image(np.zeros((H, W, 4), np.float32))
+            tracer.render_frames(p, 3)
+            assert same(tracer.read_image(W, H), acc), ("hybrid", rounds)
+            tracer.write_image(np.zeros((H, W, 4), np.float32))
+            tracer.render(p)
+            assert same(tracer.read_image(W, H), ref1), ("hybrid, one frame", rounds)
+        tracer.set_option("hybrid", 0)
         # the automatic setting (engages from eight 1920 x 1080 x 16 spp frames' worth of paths per launch: here 32
         # frames of 240 x 135 at 256 spp): against the plain kernels
         tracer.set_option("batch_frames", 32)
@@ -500,6 +512,7 @@ def test_deferred_walks_do_not_change_the_bits(rt, oracle, tracer, dragon_arrays
     finally:
         tracer.set_counters(False)
         tracer.set_option("sort_rounds", -1)
+        tracer.set_option("hybrid", 0)
         tracer.set_option("batch_frames", 16)
 
 
