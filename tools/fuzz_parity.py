@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Stress version of tests/test_gpu_scenes.py::test_random_scenes: N seeded random scenes, GPU (both kernel
 variants, with and without counters, one launch per frame; and three accumulating frames as one batch of
-rt_render_frames; and both again with the scene's biggest BVH mesh deferred to rt_walk_kernel) against the CPU oracle,
-bit for bit.  Every fourth scene is a many-mesh one (top-level trees).  usage: fuzz_parity.py [first] [count]"""
+rt_render_frames; and both again with the scene's biggest BVH mesh deferred to rt_walk_kernel, with and without the
+hybrid small blob; the general kernels where the specialised ones are the default) against the CPU oracle, bit for bit.
+Every fourth scene is a many-mesh one (top-level trees), also rendered through the wavefront sequence.  usage: fuzz_parity.py [first] [count]"""
 import os
 import sys
 
@@ -68,13 +69,45 @@ for seed in range(first, first + count):
             bad += 1
             print(f"MISMATCH seed {seed} deferred walks (single frame, counters)")
         tr.set_counters(False)
+        for hybrid in (0, 1):   # (round 3) the parking launches on the LDS-staged small blob, where the scene allows it
+            tr.set_option("hybrid", hybrid)
+            tr.write_image(np.zeros((h, w, 4), np.float32))
+            tr.render_frames(p, 3)
+            if not np.array_equal(tr.read_image(w, h).view(np.uint32), acc.view(np.uint32)):
+                bad += 1
+                print(f"MISMATCH seed {seed} deferred walks (batch, hybrid {hybrid})")
+        tr.set_option("hybrid", 0)
+        tr.set_option("sort_rounds", -1)
+        tr.set_option("defer_min_nodes", 1024)
+        # (round 3) the general kernels where the specialised instantiation is the default
+        tr.set_option("specialise", 0)
+        tr.load_scene(arrays)
         tr.write_image(np.zeros((h, w, 4), np.float32))
         tr.render_frames(p, 3)
         if not np.array_equal(tr.read_image(w, h).view(np.uint32), acc.view(np.uint32)):
             bad += 1
-            print(f"MISMATCH seed {seed} deferred walks (batch)")
-        tr.set_option("sort_rounds", -1)
-        tr.set_option("defer_min_nodes", 1024)
+            print(f"MISMATCH seed {seed} specialise = 0")
+        tr.set_option("specialise", 1)
+    else:
+        # (round 3) many-mesh scenes through the wavefront sequence: single frame with counters, and the batch
+        tr.set_option("wavefront", 1)
+        tr.set_counters(True)
+        tr.reset_timing()
+        p.frames = 0
+        tr.render(p)
+        s = tr.stats()
+        used = tr.last_launch()["wavefront"]
+        if used and not (np.array_equal(tr.read_image(w, h).view(np.uint32), ref.view(np.uint32)) and
+                         (s.segments, s.node_tests, s.triangle_tests) == (st.segments, st.node_tests, st.triangle_tests)):
+            bad += 1
+            print(f"MISMATCH seed {seed} wavefront (single frame, counters)")
+        tr.set_counters(False)
+        tr.write_image(np.zeros((h, w, 4), np.float32))
+        tr.render_frames(p, 3)
+        if not np.array_equal(tr.read_image(w, h).view(np.uint32), acc.view(np.uint32)):
+            bad += 1
+            print(f"MISMATCH seed {seed} wavefront (batch)")
+        tr.set_option("wavefront", 0)
     if (seed - first) % 50 == 49:
         print(f"... {seed - first + 1} scenes, {bad} mismatches", flush=True)
 print(f"{count} scenes, {bad} mismatches")
