@@ -237,10 +237,11 @@ def main():
     # presents every frame gets.  Outside the timed region of `value`; same barrier + synchronize bracket.
     elapsed_pf, rays_pf_local, launch_ms_pf = float("nan"), float("nan"), float("nan")
     if not args.no_per_frame_leg:
+        render(args.warmup + args.steps, 4, batch=1)       # (untimed: the pipeline's streams and scratch images are made here)
         fence()
         tracer.reset_timing()
         t1 = time.perf_counter()
-        render(args.warmup + args.steps, args.steps, batch=1)
+        render(args.warmup + args.steps + 4, args.steps, batch=1)
         fence()
         elapsed_pf = time.perf_counter() - t1
         st_pf = tracer.stats()
@@ -260,7 +261,9 @@ def main():
 
     extras = {}
     if world == 1 and rank == 0 and not args.no_extras:
-        # (outside the timed region) one launch per frame, in-place blend: what a host that shows every frame sees
+        # (outside the timed region) one launch per frame WITHOUT the pipeline (option pipeline = 0: every launch ramps up and
+        # drains alone, in-place blend) -- the latency of a frame, and what round 2 called the un-overlapped frame
+        tracer.set_option("pipeline", 0)
         seq = []
         for rep in range(3):
             tracer.synchronize()
@@ -271,6 +274,7 @@ def main():
             tracer.synchronize()
             seq.append((time.perf_counter() - t1) / 64 * 1e3)
         s1 = tracer.stats()
+        tracer.set_option("pipeline", 1)
         extras["ms_per_frame_unoverlapped"] = statistics.median(seq)
         extras["kernel_ms_unoverlapped"] = s1.kernel_ms / max(s1.launches, 1)
         # first frame after a camera change at full size: natural tile order, primary-ray table rebuilt
@@ -368,7 +372,9 @@ def main():
             "ms_per_frame_per_launch": None if args.no_per_frame_leg else elapsed_pf / args.steps * 1e3,
             "value_definition": f"value = rays of {args.steps} frames / wall time with {frames_per_launch:g} frames per launch "
                                 "(intermediate frames of a batch are not observable); value_per_frame_launch = the same frames "
-                                "with one launch" + (" and one gather" if world > 1 else "") + " per frame, timed right after",
+                                "with one launch" + (" and one gather" if world > 1 else "") + " per frame, every frame observable, timed "
+                                "right after (N = 1: consecutive launches pipelined across two internal streams, option pipeline; "
+                                "ms_per_frame_unoverlapped = the same with the pipeline off = a frame's latency)",
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "CornellBox-Original.obj/.mtl of the reference through the loader + BVH builder "
                     "(committed as tests/golden/cornell_scene.npz); no random inputs: the seed is Params.frames",

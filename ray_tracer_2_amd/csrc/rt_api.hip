@@ -85,6 +85,23 @@ struct rt_handle {
     // -- mesh records, materials, items, the small meshes' records and triangles -- as a blob of its own that the
     // parking render launches stage into LDS (they never walk the big mesh); only a winner on the big mesh reads its
     // shading record from the full blob.
+    // Pipelined single frames (option "pipeline"): consecutive rt_render calls sample into two scratch images on two
+    // internal streams and are blended in frame order on the handle's stream, so frame k + 1's launch takes the CUs that
+    // frame k's draining waves free -- every frame stays observable (rt_read_image after any call returns that frame).
+    int pipeline = 1;
+    hipStream_t pipe_stream[2] = {nullptr, nullptr};
+    hipEvent_t pipe_sampled[2] = {nullptr, nullptr};   // frame sampled into scratch[i] (recorded on pipe_stream[i])
+    hipEvent_t pipe_blended[2] = {nullptr, nullptr};   // ... and blended out of it (recorded on the handle's stream)
+    hipEvent_t pipe_book = nullptr;                    // the last tile-order / primary-table rebuild (recorded on a pipe stream)
+    hipEvent_t pipe_main = nullptr;                    // the last launch that was not pipelined (recorded on the handle's stream)
+    bool pipe_sampled_set[2] = {false, false}, pipe_blended_set[2] = {false, false}, pipe_book_set = false, pipe_main_set = false;
+    float4* pipe_scratch[2] = {nullptr, nullptr};
+    size_t pipe_scratch_texels = 0;
+    uint32_t* pipe_work[2] = {nullptr, nullptr};       // a ring of launch counters per pipe stream
+    uint32_t pipe_work_slot[2] = {0, 0};
+    uint32_t* pipe_memo = nullptr;                     // the second global-memory primary-ray memo (pixel_cache == 2)
+    size_t pipe_memo_words = 0;
+    uint32_t pipe_seq = 0;
     float4* small_blob = nullptr;
     SceneLayout small_lay{};
     uint32_t small_stack_entries = 1;
@@ -406,6 +423,19 @@ void rt_destroy(rt_handle* h) {
     free_dev(h->park_queue[0]);
     free_dev(h->park_queue[1]);
     free_dev(h->park_counts);
+    for (int k = 0; k < 2; ++k) {
+        if (h->pipe_stream[k]) {
+            (void)hipStreamSynchronize(h->pipe_stream[k]);
+            (void)hipStreamDestroy(h->pipe_stream[k]);
+        }
+        if (h->pipe_sampled[k]) (void)hipEventDestroy(h->pipe_sampled[k]);
+        if (h->pipe_blended[k]) (void)hipEventDestroy(h->pipe_blended[k]);
+        free_dev(h->pipe_scratch[k]);
+        free_dev(h->pipe_work[k]);
+    }
+    if (h->pipe_book) (void)hipEventDestroy(h->pipe_book);
+    if (h->pipe_main) (void)hipEventDestroy(h->pipe_main);
+    free_dev(h->pipe_memo);
     free_dev(h->wf_state);
     free_dev(h->wf_hit);
     free_dev(h->wf_lists);
@@ -1074,6 +1104,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "wavefront") {
         if (value < 0 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "wavefront must be 0 (off) or 1 (whenever legal)");
         h->wavefront = value;
+    } else if (n == "pipeline") {
+        h->pipeline = value ? 1 : 0;
     } else if (n == "hybrid") {
         h->hybrid = value ? 1 : 0;
     } else if (n == "lds_tlas") {
@@ -1256,43 +1288,10 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         a.pixel_cache = 2;
         a.pixel_cache_mem = h->pixel_cache_mem;
     }
-    // Primary-ray table for the memo: recomputed when the camera or the frame size changed
-    a.primary = nullptr;
-    if (h->use_primary && a.pixel_cache != 0 && params->debug_flag == 0 && params->rays_per_pixel > 0) {
-        const size_t texels = (size_t)((params->width + 7) / 8) * ((params->height + 7) / 8) * 64;  // whole 8x8 tiles
-        if (h->primary_texels < texels) {
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            free_dev(h->primary);
-            HIP_TRY(h, hipMalloc((void**)&h->primary, texels * 3 * sizeof(float)));
-            h->primary_texels = texels;
-            h->primary_valid = false;
-        }
-        if (!h->primary_valid || h->primary_w != params->width || h->primary_h != params->height ||
-            memcmp(&h->primary_camera, &h->camera, sizeof(rt_camera_uniform)) != 0) {
-            HIP_TRY(h, launch_primary(a, h->primary, h->stream));
-            h->primary_valid = true;
-            h->primary_w = params->width;
-            h->primary_h = params->height;
-            h->primary_camera = h->camera;
-        }
-        a.primary = h->primary;
-    }
-    // a fresh tile counter per launch: a ring of 64, zeroed in one go each time it wraps (launches on
-    // one stream are ordered, so every earlier user of the ring is done by then)
-    h->work_slot = (h->work_slot + 1) & 63u;
-    if (h->work_slot == 0u) HIP_TRY(h, hipMemsetAsync(h->work_counters, 0, 64 * sizeof(uint32_t), h->stream));
-    a.work_counter = h->work_counters + h->work_slot;
-    // Tile-cost feedback (persistent kernel, path-trace frames only): the tiles are handed out in the
-    // order of the rays each took in an earlier frame of the same shape, heaviest first.  Progressive
-    // accumulation re-renders the same view, so an order stays good: it is refreshed every
-    // `tile_feedback_period` frames (costs are recorded in the frame before a refresh), not every frame.
-    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
-    a.tile_order = nullptr;
-    a.tile_cost = nullptr;
-    // deferred walks (RenderArgs::park): path-trace frames of a few-mesh scene with one big mesh, persistent kernel
-    uint32_t n_rounds = h->sort_rounds > 0 ? (uint32_t)h->sort_rounds : 0u;
+    // how many rounds of deferred walks this launch would run (0: none)
     const size_t park_records = (size_t)need_texels * (n_batch ? n_batch : 1u);
     const size_t park_bytes = ((park_records + 63) / 64) * (size_t)PARK_PLANES * 64u * sizeof(float4);  // per queue
+    uint32_t n_rounds = h->sort_rounds > 0 ? (uint32_t)h->sort_rounds : 0u;
     if (h->sort_rounds < 0 && h->have_defer) {
         // (work of the launch in units of one 1920 x 1080 frame at 16 samples per pixel)
         const double units = (double)park_records * (double)(params->rays_per_pixel > 0 ? params->rays_per_pixel : 0) / (1920.0 * 1080.0 * 16.0);
@@ -1309,6 +1308,99 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     }
     bool rounds = n_rounds > 0 && h->have_defer && a.many_mesh == 0 && a.kernel_variant == 0 && params->debug_flag == 0 &&
                   params->rays_per_pixel > 0;
+    const bool wavefront_wanted = h->wavefront != 0 && a.many_mesh != 0 && !h->any_deep && params->debug_flag == 0 && params->rays_per_pixel > 0;
+    // Pipelined single frames: a plain one-frame launch of the whole image (no batch, no strips, no sequence of launches).
+    // S is the stream this frame's sampling launch and its bookkeeping run on.
+    const bool pipe = h->pipeline != 0 && n_batch == 0 && world == 1 && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
+                      !rounds && !wavefront_wanted;
+    const uint32_t pslot = h->pipe_seq & 1u;
+    hipStream_t S = h->stream;
+    bool pipe_barrier = false;  // this frame rewrites shared tables (tile order, primary rays): the other stream's frame has to be done
+    if (pipe) {
+        h->pipe_seq += 1;
+        for (int k = 0; k < 2; ++k) {
+            if (!h->pipe_stream[k]) HIP_TRY(h, hipStreamCreateWithFlags(&h->pipe_stream[k], hipStreamNonBlocking));
+            if (!h->pipe_sampled[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_sampled[k], hipEventDisableTiming));
+            if (!h->pipe_blended[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_blended[k], hipEventDisableTiming));
+            if (!h->pipe_work[k]) {
+                HIP_TRY(h, hipMalloc((void**)&h->pipe_work[k], 64 * sizeof(uint32_t)));
+                HIP_TRY(h, hipMemsetAsync(h->pipe_work[k], 0, 64 * sizeof(uint32_t), h->pipe_stream[k]));
+                h->pipe_work_slot[k] = 0;
+            }
+        }
+        if (!h->pipe_book) HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_book, hipEventDisableTiming));
+        if (!h->pipe_main) HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_main, hipEventDisableTiming));
+        if (h->pipe_scratch_texels < need_texels) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));   // (the blends on this stream wait for every sampling launch)
+            for (int k = 0; k < 2; ++k) {
+                free_dev(h->pipe_scratch[k]);
+                HIP_TRY(h, hipMalloc((void**)&h->pipe_scratch[k], need_texels * sizeof(float4)));
+            }
+            h->pipe_scratch_texels = need_texels;
+            h->pipe_blended_set[0] = h->pipe_blended_set[1] = false;
+        }
+        S = h->pipe_stream[pslot];
+        // this frame's scratch image is free once the frame before last has been blended out of it; the tables the last
+        // bookkeeping frame rewrote are complete; whatever the handle's stream did outside the pipeline is complete
+        if (h->pipe_blended_set[pslot]) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_blended[pslot], 0));
+        if (h->pipe_book_set) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_book, 0));
+        if (h->pipe_main_set) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_main, 0));
+        if (a.pixel_cache == 2u && pslot == 1u) {   // the global-memory memo is per resident wave: one per concurrent launch
+            const size_t need = (size_t)h->persistent_blocks * WAVES_PER_BLOCK * PIXEL_MEMO_DWORDS * 64u;
+            if (h->pipe_memo_words < need) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                free_dev(h->pipe_memo);
+                HIP_TRY(h, hipMalloc((void**)&h->pipe_memo, need * sizeof(uint32_t)));
+                h->pipe_memo_words = need;
+            }
+            a.pixel_cache_mem = h->pipe_memo;
+        }
+    }
+    auto barrier_other = [&]() -> hipError_t {   // before rewriting a shared table: the other stream's sampling launch is done
+        if (!pipe || pipe_barrier) return hipSuccess;
+        pipe_barrier = true;
+        return h->pipe_sampled_set[pslot ^ 1u] ? hipStreamWaitEvent(S, h->pipe_sampled[pslot ^ 1u], 0) : hipSuccess;
+    };
+    // Primary-ray table for the memo: recomputed when the camera or the frame size changed
+    a.primary = nullptr;
+    if (h->use_primary && a.pixel_cache != 0 && params->debug_flag == 0 && params->rays_per_pixel > 0) {
+        const size_t texels = (size_t)((params->width + 7) / 8) * ((params->height + 7) / 8) * 64;  // whole 8x8 tiles
+        if (h->primary_texels < texels) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            free_dev(h->primary);
+            HIP_TRY(h, hipMalloc((void**)&h->primary, texels * 3 * sizeof(float)));
+            h->primary_texels = texels;
+            h->primary_valid = false;
+        }
+        if (!h->primary_valid || h->primary_w != params->width || h->primary_h != params->height ||
+            memcmp(&h->primary_camera, &h->camera, sizeof(rt_camera_uniform)) != 0) {
+            HIP_TRY(h, barrier_other());
+            HIP_TRY(h, launch_primary(a, h->primary, S));
+            h->primary_valid = true;
+            h->primary_w = params->width;
+            h->primary_h = params->height;
+            h->primary_camera = h->camera;
+        }
+        a.primary = h->primary;
+    }
+    // a fresh tile counter per launch: a ring of 64, zeroed in one go each time it wraps (launches on
+    // one stream are ordered, so every earlier user of the ring is done by then)
+    if (pipe) {   // (a ring per pipe stream: its memset only touches launches of its own, in-order stream)
+        h->pipe_work_slot[pslot] = (h->pipe_work_slot[pslot] + 1) & 63u;
+        if (h->pipe_work_slot[pslot] == 0u) HIP_TRY(h, hipMemsetAsync(h->pipe_work[pslot], 0, 64 * sizeof(uint32_t), S));
+        a.work_counter = h->pipe_work[pslot] + h->pipe_work_slot[pslot];
+    } else {
+        h->work_slot = (h->work_slot + 1) & 63u;
+        if (h->work_slot == 0u) HIP_TRY(h, hipMemsetAsync(h->work_counters, 0, 64 * sizeof(uint32_t), h->stream));
+        a.work_counter = h->work_counters + h->work_slot;
+    }
+    // Tile-cost feedback (persistent kernel, path-trace frames only): the tiles are handed out in the
+    // order of the rays each took in an earlier frame of the same shape, heaviest first.  Progressive
+    // accumulation re-renders the same view, so an order stays good: it is refreshed every
+    // `tile_feedback_period` frames (costs are recorded in the frame before a refresh), not every frame.
+    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
+    a.tile_order = nullptr;
+    a.tile_cost = nullptr;
     // Wavefront sequence (RenderArgs::wf_*): many-mesh scenes whose meshes all walk with the ordinary stack.  One slot
     // per pixel and frame of the launch (whole 8x8 tiles); a path makes at most rays_per_pixel x (bounces + 1)
     // traversals, one per round.
@@ -1401,7 +1493,8 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             const long long per_tile = 64ll * (params->rays_per_pixel > 0 ? params->rays_per_pixel : 0) *
                                        (params->number_of_bounces >= 0 ? params->number_of_bounces + 1 : 0);
             const uint32_t max_cost = per_tile > 0xffffffffll ? 0xffffffffu : (uint32_t)per_tile;
-            HIP_TRY(h, launch_tile_order(h->tile_cost[h->cost_slot], n_tiles, max_cost, h->tile_order, h->stream));
+            HIP_TRY(h, barrier_other());
+            HIP_TRY(h, launch_tile_order(h->tile_cost[h->cost_slot], n_tiles, max_cost, h->tile_order, S));
             h->have_order = true;
             h->order_age = 0;
             h->costs_ready = false;
@@ -1411,7 +1504,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         if (!h->have_order || h->order_age + frames_now >= (uint32_t)h->tile_feedback_period) {
             h->cost_slot ^= 1;
             a.tile_cost = h->tile_cost[h->cost_slot];
-            HIP_TRY(h, hipMemsetAsync(a.tile_cost, 0, (size_t)n_tiles * sizeof(uint32_t), h->stream));
+            HIP_TRY(h, hipMemsetAsync(a.tile_cost, 0, (size_t)n_tiles * sizeof(uint32_t), S));
             h->costs_ready = true;
         }
         h->order_age += frames_now;
@@ -1447,7 +1540,11 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
                             (a.kernel_variant == 1 ? 4u : 0u) | (rounds ? 8u : 0u);
     }
     auto& ev = h->ev_pool[h->ev_used++];
-    HIP_TRY(h, hipEventRecord(ev.first, h->stream));
+    if (pipe && pipe_barrier) {   // the tables this frame rewrote: later frames of the other stream wait for them
+        HIP_TRY(h, hipEventRecord(h->pipe_book, S));
+        h->pipe_book_set = true;
+    }
+    HIP_TRY(h, hipEventRecord(ev.first, S));
     if (wavefront) {
         // shade launch 0 takes the pixels; then, round after round, the walk kernel intersects the scene for the listed
         // rays and the shade kernel finishes those segments and lists the next ones.  Everything is ordered on the
@@ -1494,6 +1591,29 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         h->last_launch[0] = (uint32_t)wlds;
         h->last_launch[1] = walk_blocks;
         h->last_launch[3] |= 16u;
+    } else if (pipe) {
+        // sample into this slot's scratch image on its stream; blend in frame order on the handle's stream
+        a.image = h->pipe_scratch[pslot];
+        a.batch_frames = 1;
+        a.batch_stride = need_texels;
+        a.batch_tile_major = 0;
+        HIP_TRY(h, launch_render(a, S));
+        HIP_TRY(h, hipEventRecord(h->pipe_sampled[pslot], S));
+        h->pipe_sampled_set[pslot] = true;
+        HIP_TRY(h, hipEventRecord(ev.second, S));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->pipe_sampled[pslot], 0));
+        BlendArgs b{};
+        b.image = h->image;
+        b.scratch = h->pipe_scratch[pslot];
+        b.texels = need_texels;
+        b.stride = need_texels;
+        b.n = 1;
+        b.frames0 = params->frames;
+        b.weight[0] = a.blend_weight;   // (wgsl:157-158 with the host's two operations, as in a one-frame launch)
+        b.rest[0] = a.blend_rest;
+        HIP_TRY(h, launch_blend_frames(b, h->stream));
+        HIP_TRY(h, hipEventRecord(h->pipe_blended[pslot], h->stream));
+        h->pipe_blended_set[pslot] = true;
     } else if (!rounds) {
         HIP_TRY(h, launch_render(a, h->stream));
     } else {
@@ -1586,7 +1706,13 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         }
         HIP_TRY(h, launch_blend_frames(b, h->stream));
     }
-    HIP_TRY(h, hipEventRecord(ev.second, h->stream));
+    if (!pipe) {
+        HIP_TRY(h, hipEventRecord(ev.second, h->stream));
+        if (h->pipe_stream[0]) {   // (pipelined frames may follow: their streams wait for this launch)
+            HIP_TRY(h, hipEventRecord(h->pipe_main, h->stream));
+            h->pipe_main_set = true;
+        }
+    }
     h->launches_total += 1;
     h->frames_total += n_batch ? n_batch : 1u;
     if (params->debug_flag == 0 && params->rays_per_pixel > 0) {

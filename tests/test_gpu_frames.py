@@ -332,3 +332,71 @@ def test_independent_frames_pipelined_across_two_handles(rt, oracle, cornell):
     finally:
         for h in hs:
             h.close()
+
+
+def test_pipelined_single_frames(rt, oracle, tracer, cornell):
+    """Option pipeline (default on): consecutive rt_render calls sample into two scratch images on two internal streams and
+    are blended in frame order on the handle's stream.  Forty frames without a synchronisation in between -- across tile-order
+    refreshes (every 8 frames), a camera change (primary-ray table rebuilt), a change of frame size, a batch in the middle,
+    an image written by the host -- equal the same calls with the pipeline off, and the first frames equal the oracle's;
+    every frame is observable: reading after any call returns that frame."""
+    w, h = 200, 104
+
+    def script(t):
+        t.write_image(np.zeros((h, w, 4), np.float32))
+        out = []
+        for f in range(20):
+            t.render(rt.make_params(w, h, 4, 3, skybox=1, frames=f))
+            if f in (0, 1, 2, 9):
+                out.append(t.read_image(w, h).copy())          # (observable at any point)
+        cam = type(cornell.uniform.camera).from_buffer_copy(bytes(cornell.uniform.camera))
+        cam.cam_to_world[3][0] += 0.05
+        t.set_camera(cam)                                       # accumulation restarts: frames = 0 stores
+        for f in range(12):
+            t.render(rt.make_params(w, h, 4, 3, skybox=1, frames=f))
+        t.render_frames(rt.make_params(w, h, 4, 3, skybox=1, frames=12), 5)   # a batch on the handle's stream in between
+        for f in range(17, 25):
+            t.render(rt.make_params(w, h, 4, 3, skybox=1, frames=f))
+        out.append(t.read_image(w, h).copy())
+        for f in range(6):                                      # another frame size: the scratch images are re-made
+            t.render(rt.make_params(96, 54, 3, 2, skybox=1, frames=f))
+        out.append(t.read_image(96, 54).copy())
+        t.set_camera(cornell.uniform.camera)
+        return out
+
+    tracer.load_scene(cornell)
+    try:
+        tracer.set_option("pipeline", 0)
+        want = script(tracer)
+        tracer.set_option("pipeline", 1)
+        got = script(tracer)
+    finally:
+        tracer.set_option("pipeline", 1)
+    assert len(got) == len(want)
+    for k, (g, wnt) in enumerate(zip(got, want)):
+        assert np.array_equal(bits(g), bits(wnt)), k
+    ref = np.zeros((h, w, 4), np.float32)
+    for f in range(3):
+        ref, _ = oracle.render(rt.make_params(w, h, 4, 3, skybox=1, frames=f), cornell, image=ref)
+        assert np.array_equal(bits(got[f]), bits(ref)), f
+
+
+def test_pipelined_single_frames_global_memory_scene(rt, tracer):
+    """The same on a scene read from global memory (its primary-ray memo lives in global memory, one buffer per
+    concurrent launch) and on a many-mesh textured scene: 12 frames, pipeline on == off."""
+    from ray_tracer_2_amd import scenes
+    w, h = 160, 90
+    for arrays in (rt.SceneArrays.from_scene(scenes.sponza_standin(340, detail=8)), rt.SceneArrays.from_scene(scenes.sponza_standin(200))):
+        tracer.load_scene(arrays)
+        outs = []
+        try:
+            for pipe in (0, 1):
+                tracer.set_option("pipeline", pipe)
+                tracer.write_image(np.zeros((h, w, 4), np.float32))
+                tracer.reset_timing()
+                for f in range(12):
+                    tracer.render(rt.make_params(w, h, 3, 2, skybox=1, frames=f))
+                outs.append((tracer.read_image(w, h).copy(), tracer.stats().segments))
+        finally:
+            tracer.set_option("pipeline", 1)
+        assert np.array_equal(bits(outs[0][0]), bits(outs[1][0])) and outs[0][1] == outs[1][1]

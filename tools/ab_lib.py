@@ -53,9 +53,13 @@ def child(a):
     run(0, max(a.batch, 8))     # warm-up (tile order, tables)
     tr.synchronize()
     tr.reset_timing()
+    import time
+    t0 = time.perf_counter()
     run(max(a.batch, 8), a.frames)
+    tr.synchronize()
+    wall = (time.perf_counter() - t0) / a.frames * 1e3
     st = tr.stats()
-    print(json.dumps({"ms_per_frame": st.kernel_ms / st.frames, "segments_per_frame": st.segments / st.frames,
+    print(json.dumps({"ms_per_frame": st.kernel_ms / st.frames, "wall_ms_per_frame": wall, "segments_per_frame": st.segments / st.frames,
                       "launches": st.launches, "launch": tr.last_launch() if hasattr(tr, "last_launch") else None}), flush=True)
     tr.close()
 
@@ -78,7 +82,7 @@ def main():
         return child(a)
     libs = a.libs or [os.path.join(ROOT, "ray_tracer_2_amd", "librt2_mi355x.so")]
     times = {l: [] for l in libs}
-    segs, info = {}, {}
+    segs, info, walls = {}, {}, {}
     for r in range(a.rounds):
         for l in libs:
             path, _, own = l.partition(":")
@@ -92,12 +96,13 @@ def main():
                 continue
             d = json.loads(out.stdout.strip().splitlines()[-1])
             times[l].append(d["ms_per_frame"])
+            walls.setdefault(l, []).append(d.get("wall_ms_per_frame", float("nan")))
             segs[l] = d["segments_per_frame"]
             info[l] = d.get("launch")
     print(f"scene {a.scene} {a.w}x{a.h} {a.spp} spp {a.bounces} bounces, {a.batch} frames per launch, {a.frames} frames x {a.rounds} rounds")
     for l in libs:
         if times[l]:
-            print(f"{os.path.basename(l):60s} median {statistics.median(times[l]):8.4f}  min {min(times[l]):8.4f} ms/frame   rays/frame {segs[l]:.0f}  {info.get(l)}", flush=True)
+            print(f"{os.path.basename(l):60s} median {statistics.median(times[l]):8.4f}  min {min(times[l]):8.4f} ms/frame (sum of launch times; wall {statistics.median(walls[l]):.4f})   rays/frame {segs[l]:.0f}  {info.get(l)}", flush=True)
 
 
 if __name__ == "__main__":
