@@ -1309,10 +1309,10 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     bool rounds = n_rounds > 0 && h->have_defer && a.many_mesh == 0 && a.kernel_variant == 0 && params->debug_flag == 0 &&
                   params->rays_per_pixel > 0;
     const bool wavefront_wanted = h->wavefront != 0 && a.many_mesh != 0 && !h->any_deep && params->debug_flag == 0 && params->rays_per_pixel > 0;
-    // Pipelined single frames: a plain one-frame launch of the whole image (no batch, no strips, no sequence of launches).
+    // Pipelined single frames: a plain one-frame launch (no batch, no sequence of launches).
     // S is the stream this frame's sampling launch and its bookkeeping run on.
-    const bool pipe = h->pipeline != 0 && n_batch == 0 && world == 1 && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
-                      !rounds && !wavefront_wanted;
+    const bool pipe = h->pipeline != 0 && n_batch == 0 && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
+                      !rounds && !wavefront_wanted;   // (strips too: the gather reads the image behind the blend, on the handle's stream)
     const uint32_t pslot = h->pipe_seq & 1u;
     hipStream_t S = h->stream;
     bool pipe_barrier = false;  // this frame rewrites shared tables (tile order, primary rays): the other stream's frame has to be done
