@@ -85,22 +85,22 @@ struct rt_handle {
     // -- mesh records, materials, items, the small meshes' records and triangles -- as a blob of its own that the
     // parking render launches stage into LDS (they never walk the big mesh); only a winner on the big mesh reads its
     // shading record from the full blob.
-    // Pipelined single frames (option "pipeline"): consecutive rt_render calls sample into two scratch images on two
-    // internal streams and are blended in frame order on the handle's stream, so frame k + 1's launch takes the CUs that
+    // Pipelined single frames (option "pipeline"): consecutive rt_render calls sample into two or three scratch images, each
+    // on an internal stream of its own, and are blended in frame order on the handle's stream, so frame k + 1's launch takes the CUs that
     // frame k's draining waves free -- every frame stays observable (rt_read_image after any call returns that frame).
-    int pipeline = 1;
-    hipStream_t pipe_stream[2] = {nullptr, nullptr};
-    hipEvent_t pipe_sampled[2] = {nullptr, nullptr};   // frame sampled into scratch[i] (recorded on pipe_stream[i])
-    hipEvent_t pipe_blended[2] = {nullptr, nullptr};   // ... and blended out of it (recorded on the handle's stream)
+    int pipeline = 3;                                  // option "pipeline": frames in flight (0 = off, 2, 3; config 2: 1.59 / 1.34 / 1.30 ms per frame)
+    hipStream_t pipe_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t pipe_sampled[3] = {nullptr, nullptr, nullptr};   // frame sampled into scratch[i] (recorded on pipe_stream[i])
+    hipEvent_t pipe_blended[3] = {nullptr, nullptr, nullptr};   // ... and blended out of it (recorded on the handle's stream)
     hipEvent_t pipe_book = nullptr;                    // the last tile-order / primary-table rebuild (recorded on a pipe stream)
     hipEvent_t pipe_main = nullptr;                    // the last launch that was not pipelined (recorded on the handle's stream)
-    bool pipe_sampled_set[2] = {false, false}, pipe_blended_set[2] = {false, false}, pipe_book_set = false, pipe_main_set = false;
-    float4* pipe_scratch[2] = {nullptr, nullptr};
+    bool pipe_sampled_set[3] = {false, false, false}, pipe_blended_set[3] = {false, false, false}, pipe_book_set = false, pipe_main_set = false;
+    float4* pipe_scratch[3] = {nullptr, nullptr, nullptr};
     size_t pipe_scratch_texels = 0;
-    uint32_t* pipe_work[2] = {nullptr, nullptr};       // a ring of launch counters per pipe stream
-    uint32_t pipe_work_slot[2] = {0, 0};
-    uint32_t* pipe_memo = nullptr;                     // the second global-memory primary-ray memo (pixel_cache == 2)
-    size_t pipe_memo_words = 0;
+    uint32_t* pipe_work[3] = {nullptr, nullptr, nullptr};       // a ring of launch counters per pipe stream
+    uint32_t pipe_work_slot[3] = {0, 0, 0};
+    uint32_t* pipe_memo[3] = {nullptr, nullptr, nullptr};       // further global-memory primary-ray memos (pixel_cache == 2)
+    size_t pipe_memo_words[3] = {0, 0, 0};
     uint32_t pipe_seq = 0;
     float4* small_blob = nullptr;
     SceneLayout small_lay{};
@@ -423,7 +423,8 @@ void rt_destroy(rt_handle* h) {
     free_dev(h->park_queue[0]);
     free_dev(h->park_queue[1]);
     free_dev(h->park_counts);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
+        free_dev(h->pipe_memo[k]);
         if (h->pipe_stream[k]) {
             (void)hipStreamSynchronize(h->pipe_stream[k]);
             (void)hipStreamDestroy(h->pipe_stream[k]);
@@ -435,7 +436,6 @@ void rt_destroy(rt_handle* h) {
     }
     if (h->pipe_book) (void)hipEventDestroy(h->pipe_book);
     if (h->pipe_main) (void)hipEventDestroy(h->pipe_main);
-    free_dev(h->pipe_memo);
     free_dev(h->wf_state);
     free_dev(h->wf_hit);
     free_dev(h->wf_lists);
@@ -1105,7 +1105,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         if (value < 0 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "wavefront must be 0 (off) or 1 (whenever legal)");
         h->wavefront = value;
     } else if (n == "pipeline") {
-        h->pipeline = value ? 1 : 0;
+        if (value < 0 || value > 3) return fail(h, RT_ERR_INVALID_ARGUMENT, "pipeline must be 0 (off), 2 or 3 (frames in flight)");
+        h->pipeline = value == 1 ? 3 : value;
     } else if (n == "hybrid") {
         h->hybrid = value ? 1 : 0;
     } else if (n == "lds_tlas") {
@@ -1311,14 +1312,15 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     const bool wavefront_wanted = h->wavefront != 0 && a.many_mesh != 0 && !h->any_deep && params->debug_flag == 0 && params->rays_per_pixel > 0;
     // Pipelined single frames: a plain one-frame launch (no batch, no sequence of launches).
     // S is the stream this frame's sampling launch and its bookkeeping run on.
+    const uint32_t pipe_depth = h->pipeline >= 3 ? 3u : 2u;
     const bool pipe = h->pipeline != 0 && n_batch == 0 && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
                       !rounds && !wavefront_wanted;   // (strips too: the gather reads the image behind the blend, on the handle's stream)
-    const uint32_t pslot = h->pipe_seq & 1u;
+    const uint32_t pslot = h->pipe_seq % pipe_depth;
     hipStream_t S = h->stream;
     bool pipe_barrier = false;  // this frame rewrites shared tables (tile order, primary rays): the other stream's frame has to be done
     if (pipe) {
-        h->pipe_seq += 1;
-        for (int k = 0; k < 2; ++k) {
+        h->pipe_seq = (h->pipe_seq + 1) % 6u;
+        for (int k = 0; k < 3; ++k) {
             if (!h->pipe_stream[k]) HIP_TRY(h, hipStreamCreateWithFlags(&h->pipe_stream[k], hipStreamNonBlocking));
             if (!h->pipe_sampled[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_sampled[k], hipEventDisableTiming));
             if (!h->pipe_blended[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_blended[k], hipEventDisableTiming));
@@ -1332,12 +1334,12 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         if (!h->pipe_main) HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_main, hipEventDisableTiming));
         if (h->pipe_scratch_texels < need_texels) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));   // (the blends on this stream wait for every sampling launch)
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < 3; ++k) {
                 free_dev(h->pipe_scratch[k]);
                 HIP_TRY(h, hipMalloc((void**)&h->pipe_scratch[k], need_texels * sizeof(float4)));
+                h->pipe_blended_set[k] = false;
             }
             h->pipe_scratch_texels = need_texels;
-            h->pipe_blended_set[0] = h->pipe_blended_set[1] = false;
         }
         S = h->pipe_stream[pslot];
         // this frame's scratch image is free once the frame before last has been blended out of it; the tables the last
@@ -1345,21 +1347,26 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         if (h->pipe_blended_set[pslot]) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_blended[pslot], 0));
         if (h->pipe_book_set) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_book, 0));
         if (h->pipe_main_set) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_main, 0));
-        if (a.pixel_cache == 2u && pslot == 1u) {   // the global-memory memo is per resident wave: one per concurrent launch
+        if (a.pixel_cache == 2u && pslot != 0u) {   // the global-memory memo is per resident wave: one per concurrent launch
             const size_t need = (size_t)h->persistent_blocks * WAVES_PER_BLOCK * PIXEL_MEMO_DWORDS * 64u;
-            if (h->pipe_memo_words < need) {
+            if (h->pipe_memo_words[pslot] < need) {
                 HIP_TRY(h, hipStreamSynchronize(h->stream));
-                free_dev(h->pipe_memo);
-                HIP_TRY(h, hipMalloc((void**)&h->pipe_memo, need * sizeof(uint32_t)));
-                h->pipe_memo_words = need;
+                free_dev(h->pipe_memo[pslot]);
+                HIP_TRY(h, hipMalloc((void**)&h->pipe_memo[pslot], need * sizeof(uint32_t)));
+                h->pipe_memo_words[pslot] = need;
             }
-            a.pixel_cache_mem = h->pipe_memo;
+            a.pixel_cache_mem = h->pipe_memo[pslot];
         }
     }
     auto barrier_other = [&]() -> hipError_t {   // before rewriting a shared table: the other stream's sampling launch is done
         if (!pipe || pipe_barrier) return hipSuccess;
         pipe_barrier = true;
-        return h->pipe_sampled_set[pslot ^ 1u] ? hipStreamWaitEvent(S, h->pipe_sampled[pslot ^ 1u], 0) : hipSuccess;
+        for (uint32_t k = 0; k < 3u; ++k)
+            if (k != pslot && h->pipe_sampled_set[k]) {
+                const hipError_t e = hipStreamWaitEvent(S, h->pipe_sampled[k], 0);
+                if (e != hipSuccess) return e;
+            }
+        return hipSuccess;
     };
     // Primary-ray table for the memo: recomputed when the camera or the frame size changed
     a.primary = nullptr;

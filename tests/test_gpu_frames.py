@@ -335,8 +335,8 @@ def test_independent_frames_pipelined_across_two_handles(rt, oracle, cornell):
 
 
 def test_pipelined_single_frames(rt, oracle, tracer, cornell):
-    """Option pipeline (default on): consecutive rt_render calls sample into two scratch images on two internal streams and
-    are blended in frame order on the handle's stream.  Forty frames without a synchronisation in between -- across tile-order
+    """Option pipeline (default: three frames in flight): consecutive rt_render calls sample into scratch images on internal
+    streams and are blended in frame order on the handle's stream.  Forty frames without a synchronisation in between -- across tile-order
     refreshes (every 8 frames), a camera change (primary-ray table rebuilt), a change of frame size, a batch in the middle,
     an image written by the host -- equal the same calls with the pipeline off, and the first frames equal the oracle's;
     every frame is observable: reading after any call returns that frame."""
@@ -368,13 +368,14 @@ def test_pipelined_single_frames(rt, oracle, tracer, cornell):
     try:
         tracer.set_option("pipeline", 0)
         want = script(tracer)
-        tracer.set_option("pipeline", 1)
-        got = script(tracer)
+        for depth in (2, 3):   # frames in flight
+            tracer.set_option("pipeline", depth)
+            got = script(tracer)
+            assert len(got) == len(want)
+            for k, (g, wnt) in enumerate(zip(got, want)):
+                assert np.array_equal(bits(g), bits(wnt)), (depth, k)
     finally:
         tracer.set_option("pipeline", 1)
-    assert len(got) == len(want)
-    for k, (g, wnt) in enumerate(zip(got, want)):
-        assert np.array_equal(bits(g), bits(wnt)), k
     ref = np.zeros((h, w, 4), np.float32)
     for f in range(3):
         ref, _ = oracle.render(rt.make_params(w, h, 4, 3, skybox=1, frames=f), cornell, image=ref)
@@ -390,7 +391,7 @@ def test_pipelined_single_frames_global_memory_scene(rt, tracer):
         tracer.load_scene(arrays)
         outs = []
         try:
-            for pipe in (0, 1):
+            for pipe in (0, 3):
                 tracer.set_option("pipeline", pipe)
                 tracer.write_image(np.zeros((h, w, 4), np.float32))
                 tracer.reset_timing()
