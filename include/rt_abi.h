@@ -178,7 +178,8 @@ typedef struct rt_stats {
     uint64_t paths;
     uint64_t node_tests;     /* AABB tests, as wgsl:322 counts them */
     uint64_t triangle_tests; /* as wgsl:307 counts them */
-    float kernel_ms;         /* sum of the hipEvent times of `launches` render launches */
+    float kernel_ms;         /* sum of the hipEvent times of `launches` render launches (pipelined single frames --
+                              * option "pipeline" -- overlap: their sum then exceeds the wall time) */
     uint32_t launches;       /* render launches since the last rt_reset_timing */
     uint32_t frames;         /* frames those launches rendered (rt_render_frames: several per launch) */
     uint64_t segments_reused; /* of `segments`: primary segments whose hit was taken from the per-pixel memo

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Compute part of the multi-GPU strip split, measured on ONE GPU: rank 0's share of the config-2
-frame (8-row strips dealt round-robin) for world = 1, 2, 4, 8, one launch per frame and with frames
-overlapped (rt_render_strips_frames, 16 frames per launch).  Predicts the compute-only scaling; the
+frame (8-row strips dealt round-robin) for world = 1, 2, 4, 8: one launch per frame with and without the
+pipeline, and with frames overlapped (rt_render_strips_frames, 32 frames per launch); wall time per frame.  Predicts the compute-only scaling; the
 gather (<= 4.2 MB per rank per batch over xGMI) is not included."""
 import os
 import statistics
@@ -11,24 +11,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ray_tracer_2_amd as rt  # noqa: E402
 
+import time  # noqa: E402
+
 W, H, N = 1920, 1080, 64
 arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
 tr = rt.RayTracer(0, W, H)
 tr.load_scene(arrays)
 base = {}
-for batch in (1, 16):
+# (mode, frames per launch, option pipeline): wall time per frame -- pipelined launches overlap, their event times do not add up
+for mode, batch, pipe in (("one launch per frame, no pipeline", 1, 0), ("one launch per frame, pipelined (default)", 1, 3),
+                          ("32 frames per launch", 32, 3)):
     tr.set_option("batch_frames", batch)
+    tr.set_option("pipeline", pipe)
     for world in (1, 2, 4, 8):
         ts = []
         for r in range(4):
-            tr.reset_timing()
+            tr.synchronize()
+            t0 = time.perf_counter()
             tr.render_strips_frames(rt.make_params(W, H, 4, 8, skybox=1, frames=1), N, 0, world)
-            st = tr.stats()
+            tr.synchronize()
             if r:
-                ts.append(st.kernel_ms / st.frames)
+                ts.append((time.perf_counter() - t0) / N * 1e3)
         t = statistics.median(ts)
         if world == 1:
-            base[batch] = t
-        mode = "one launch per frame" if batch == 1 else f"{batch} frames per launch"
-        print(f"{mode:22s} world {world}: {t:.3f} ms per frame for rank 0's share -> compute-only speed-up {base[batch] / t:.2f}x "
-              f"(vs the un-overlapped 1-GPU frame: {base[1] / t:.2f}x)", flush=True)
+            base[mode] = t
+        print(f"{mode:42s} world {world}: {t:.3f} ms per frame for rank 0's share -> compute-only speed-up {base[mode] / t:.2f}x", flush=True)
