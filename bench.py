@@ -52,6 +52,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (before anything initialises the HIP runtime: the library's pipelined frames want a hardware queue per stream, see
+# ray_tracer_2_amd/__init__.py; a setting of the caller's wins)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 WIDTH, HEIGHT, SPP, BOUNCES = 1920, 1080, 8, 4
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
