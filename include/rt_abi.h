@@ -296,8 +296,10 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 fits (else global memory) / always in global memory
  *   primary_table         0 / 1 (1)               0: compute the memoised primary ray per pixel in the render kernel
  *                                                 instead of once per (camera, frame size)
- *   vote_eighths          0..8 (6)                intersection vote: traverse when wanting lanes x 8 >= lanes x this
- *   vote_patience         >= 0 (3)                ... or when some lane has waited this many iterations
+ *   vote_eighths          -1 / 0..8 (-1)          intersection vote: traverse when wanting lanes x 8 >= lanes x this
+ *   vote_patience         -1 / >= 0 (-1)          ... or when some lane has waited this many iterations; -1: by the kind of
+ *                                                 launch (6 and 3 for a scene in LDS on the few-mesh kernels, 7 and 16 for
+ *                                                 the others, 8 and 16 inside a deferred-walk sequence)
  *   tile_feedback         0 / 1 (1)               order the tiles by an earlier frame's rays per tile, heaviest first
  *   tile_feedback_period  >= 1 (8)                frames an order is kept before it is refreshed
  *   pipeline              0 / 2 / 3 (3)           frames in flight: consecutive rt_render calls sample into that many scratch images,
@@ -323,6 +325,8 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 for that many rounds; -1: by the work of the launch and the mesh's size,
  *                                                 and only while both park queues fit a quarter of the free memory
  *   defer_min_nodes       >= 1 (1024) (upload)    smallest BVH (internal nodes) whose mesh may be the deferred one
+ *   park_levels           0 / 1 (1)               a parking launch runs the deferred walk's first two levels inline and parks
+ *                                                 only the rays that reach a grandchild box (0: every ray that can hit the root box)
  *   hybrid                0 / 1 (0)               the parking launches of a deferred-walk sequence stage everything but the big
  *                                                 mesh into LDS (measured no faster: DESIGN.md section 5.4)
  *   wavefront             0 / 1 (0)               wavefront sequences (many-mesh scenes): path state in memory slots, a shading

@@ -136,6 +136,7 @@ struct rt_handle {
     // two workgroups per CU, 10.64 -> 13.47 ms; the 42 top records that fit at full occupancy make every tree fetch a
     // two-path load, 10.67 -> 11.98 ms)
     int lds_tlas = 0;
+    int park_levels = 1;  // option "park_levels": the parking launches run the deferred walk's first two levels inline
     uint32_t n_tlas_records = 0;
     float4* own_image = nullptr;  // allocated by rt_create; `image` may be rebound
     float4* multi_gathered = nullptr;  // rt_render_multi root: [world][pad_texels]
@@ -192,7 +193,7 @@ struct rt_handle {
     bool plain_materials = false;  // no spheres, no glass, no textured material (rt_upload_scene)
     int specialise = 1;            // option "specialise": 0 = always the general kernels
     int pixel_cache_opt = 1;  // option "pixel_cache"
-    int vote_eighths = 6, vote_patience = 3;  // options "vote_eighths", "vote_patience"
+    int vote_eighths = -1, vote_patience = -1;  // options "vote_eighths", "vote_patience" (-1: by the kind of launch, render_impl)
     int use_tlas = 1;  // option "tlas": 0 = every mesh is a single item (takes effect at the next upload)
     int use_forest = 1;  // option "forest": 0 = no forest items (takes effect at the next upload)
     int use_flat2 = 1;   // option "flat2": 0 = meshes with a two-leaf BVH are not run as straight-line items (next upload)
@@ -1075,10 +1076,10 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         h->tile_feedback_period = value;
         h->history_valid = false;
     } else if (n == "vote_eighths") {
-        if (value < 0 || value > 8) return fail(h, RT_ERR_INVALID_ARGUMENT, "vote_eighths must be 0..8");
+        if (value < -1 || value > 8) return fail(h, RT_ERR_INVALID_ARGUMENT, "vote_eighths must be -1 (automatic) or 0..8");
         h->vote_eighths = value;
     } else if (n == "vote_patience") {
-        if (value < 0) return fail(h, RT_ERR_INVALID_ARGUMENT, "vote_patience must be >= 0");
+        if (value < -1) return fail(h, RT_ERR_INVALID_ARGUMENT, "vote_patience must be -1 (automatic) or >= 0");
         h->vote_patience = value;
     } else if (n == "pixel_cache") {
         if (value < 0 || value > 2) return fail(h, RT_ERR_INVALID_ARGUMENT, "pixel_cache must be 0, 1 or 2 (memo in global memory)");
@@ -1115,6 +1116,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "pipeline") {
         if (value < 0 || value > 3) return fail(h, RT_ERR_INVALID_ARGUMENT, "pipeline must be 0 (off), 2 or 3 (frames in flight)");
         h->pipeline = value == 1 ? 3 : value;
+    } else if (n == "park_levels") {
+        h->park_levels = value ? 1 : 0;
     } else if (n == "hybrid") {
         h->hybrid = value ? 1 : 0;
     } else if (n == "lds_tlas") {
@@ -1244,8 +1247,6 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
                                               : ((uint64_t)a.tiles_x * a.tiles_y * 4 <= (uint64_t)resident_waves * 5 ? 1u : 0u);
     if (n_batch) a.kernel_variant = 0;  // (frame, tile) work items are the persistent kernel's
     // (all fields that size the LDS are set by now)
-    a.vote_eighths = (uint32_t)h->vote_eighths;
-    a.vote_patience = (uint32_t)h->vote_patience;
     a.pixel_cache = 0;
     a.pixel_cache_mem = nullptr;
     if (h->pixel_cache_opt == 1) {
@@ -1317,6 +1318,17 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     }
     bool rounds = n_rounds > 0 && h->have_defer && a.many_mesh == 0 && a.kernel_variant == 0 && params->debug_flag == 0 &&
                   params->rays_per_pixel > 0;
+    // The intersection vote (path_begin).  The more a traversal costs beside the rest of an iteration, the longer it pays
+    // to let the lanes on memoised primary segments catch up first: 6/8 of the lanes or 3 iterations when the scene is in
+    // LDS and walked by the few-mesh kernels (config 2: 1.221 ms per frame; 1.222 with 7/8 and 16, 1.366 with 8/8), 7/8 or
+    // 16 iterations otherwise (sponza-sized stand-in 10.69 -> 10.21 ms, 200-mesh stand-in 5.00 -> 4.85), every lane or 16
+    // iterations in a deferred-walk sequence, whose resumed pixels arrive in every phase (config 3 stand-in 5.86 -> 5.45,
+    // config 5 geometry 3.35 -> 3.22; gpurun_out/r3w/ab_*_vote*.txt).
+    {
+        const bool costly = a.lds_scene == 0u || a.many_mesh != 0u;
+        a.vote_eighths = h->vote_eighths >= 0 ? (uint32_t)h->vote_eighths : rounds ? 8u : costly ? 7u : 6u;
+        a.vote_patience = h->vote_patience >= 0 ? (uint32_t)h->vote_patience : (rounds || costly) ? 16u : 3u;
+    }
     const bool wavefront_wanted = h->wavefront != 0 && a.many_mesh != 0 && !h->any_deep && params->debug_flag == 0 && params->rays_per_pixel > 0;
     // Pipelined single frames: a plain one-frame launch (no batch, no sequence of launches).
     // S is the stream this frame's sampling launch and its bookkeeping run on.
@@ -1651,6 +1663,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         };
         const uint32_t R = n_rounds;
         a.park = 1;
+        a.park_levels = (uint32_t)h->park_levels;
         a.q_in = nullptr;
         a.q_in_count = nullptr;
         a.q_out = h->park_queue[0];
@@ -1679,6 +1692,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             if (!ah.pixel_cache) ah.primary = nullptr;
             if (render_lds_bytes(ah) > LDS_BUDGET_BYTES) hybrid = false;
             ah.persistent_blocks = h->persistent_blocks;
+            ah.park_levels = 0;  // (the small blob has no record of the big mesh's BVH)
         }
         if (!hybrid) ah = a;
         auto sync_queues = [&]() {  // (the queue fields move with the rounds: keep the hybrid copy's in step)

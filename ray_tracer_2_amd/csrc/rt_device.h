@@ -205,6 +205,7 @@ struct RenderArgs {
     // the undeferred loop, so the image is the same bit for bit; the last launch of a sequence has park = 0 and
     // walks what is left inline.
     uint32_t park;
+    uint32_t park_levels;         // != 0: a ray parks only if the walk's first two levels reach a grandchild box (option "park_levels")
     float4* q_in;                 // park records to resume instead of tiles (null: the work items are tiles)
     const uint32_t* q_in_count;   // their number (written by the launch before)
     float4* q_out;                // where this launch parks

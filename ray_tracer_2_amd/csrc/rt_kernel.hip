@@ -859,9 +859,44 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                                             rtm::abs_(lo.x) < INF && rtm::abs_(lo.y) < INF && rtm::abs_(lo.z) < INF;
                     const uint32_t mo = a.lay.mesh_off + ia * MESH_REC_BYTES;
                     may_hit = !finite_ray || aabb_dist(lo, inv, ld4<LDS>(a, mo + 160), ld4<LDS>(a, mo + 176), INF) < INF;
+                    if (STATS && !may_hit) node_tests += 2;  // the shader's two root-level tests (wgsl:322)
+                    if (finite_ray && may_hit && a.park_levels != 0u) {
+                        // The walk's first two levels, inline: until it reaches a leaf the walk's closest distance
+                        // is INF, so these ARE its tests (wgsl:316-327) -- a ray that misses the root's children, or
+                        // the children of those it hits, ends its walk there without a hit and need not park.
+                        // (The root box is 12-22 % looser than its four grandchildren for the stand-ins' rays.)
+                        float4 q0, q1, q2, q3;
+                        load_wide<LDS>(a, fbits(hdr.y), q0, q1, q2, q3);
+                        const bool hit_a = aabb_dist(lo, inv, q0, q1, INF) < INF, hit_b = aabb_dist(lo, inv, q2, q3, INF) < INF;
+                        int tests = 2;
+                        bool reaches = false;
+                        if (hit_a) {
+                            if (fbits(q1.w) != 0u) {
+                                reaches = true;
+                            } else {
+                                float4 r0, r1, r2, r3;
+                                load_wide<LDS>(a, fbits(q1.z), r0, r1, r2, r3);
+                                reaches = aabb_dist(lo, inv, r0, r1, INF) < INF || aabb_dist(lo, inv, r2, r3, INF) < INF;
+                                tests += 2;
+                            }
+                        }
+                        if (hit_b && !reaches) {
+                            if (fbits(q3.w) != 0u) {
+                                reaches = true;
+                            } else {
+                                float4 r0, r1, r2, r3;
+                                load_wide<LDS>(a, fbits(q3.z), r0, r1, r2, r3);
+                                reaches = aabb_dist(lo, inv, r0, r1, INF) < INF || aabb_dist(lo, inv, r2, r3, INF) < INF;
+                                tests += 2;
+                            }
+                        }
+                        if (!reaches) {
+                            may_hit = false;
+                            if (STATS) node_tests += tests;
+                        }
+                    }
                 }
                 if (may_hit) suspended = true;
-                else if (STATS) node_tests += 2;  // the shader's two root-level tests (wgsl:322)
                 continue;
             }
             if (kind & ITEM_FLAT2) {
@@ -1594,6 +1629,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
             if (a.park != 0u) {  // (wave-uniform)
                 // park the suspended lanes' pixels: consecutive records, one counter update per wave
                 const unsigned long long here = __ballot(true), parking = __ballot(hit.suspended);
+                TIC(t20);
                 if (parking != 0ull) {
                     uint32_t slot0 = 0;
                     if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(here)) slot0 = atomicAdd(a.q_out_count, (uint32_t)__popcll(parking));
@@ -1602,15 +1638,18 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(parking >> 32),
                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)parking, 0u));
                         park_store<total_in_lds(LDS)>(a, slot0 + rank, s, ls, I);
+                        TOC(t20, 20);
                         return PATH_PARK;
                     }
                 }
+                TOC(t20, 20);
             }
         }
         memo_hit_store<STATS>(a, s, ls, hit);
     } else if (PARK && !TLAS && mode == STEP_RESUME) {
         // behind the deferred mesh's walk: offer the walk's hit (the local ray: the operations of ITEM_NEW_XFORM),
         // finish the segment
+        TIC(t22);
         Isect I;
         CompactHit walked;
         park_load_hit(a, resume_slot, I, walked);
@@ -1626,6 +1665,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
         }
         hit = isect_finish<LDS, SIMPLE, HYB>(a, I, s.ro, s.rd);
         memo_hit_store<STATS>(a, s, ls, hit);
+        TOC(t22, 22);
     }
     return path_end<LDS, total_in_lds(LDS), SIMPLE>(a, s, ls, mode, hit, n_segments) ? PATH_PIXEL_DONE : PATH_CONTINUE;
 }
@@ -1876,9 +1916,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (!active && rank < pool_left && resuming) {
                     if constexpr (PARK) {  // resume a parked pixel (path_step finishes its segment)
+                        TIC(t21);
                         resume_slot = pool_base + rank;
                         park_load<total_in_lds(LDS)>(a, resume_slot, s, ls);
                         active = true;
+                        TOC(t21, 21);
                     }
                 } else if (!active && rank < pool_left) {
                     const uint32_t q = pool_base + rank;

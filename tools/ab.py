@@ -15,7 +15,7 @@ import ray_tracer_2_amd as rt  # noqa: E402
 
 ALIAS = {"variant": "kernel_variant", "blocks": "persistent_blocks", "lds": "lds_scene", "fb": "tile_feedback", "cull": "cull_roots", "pc": "pixel_cache", "ve": "vote_eighths", "vp": "vote_patience"}
 UPLOAD_OPTS = {"tlas", "tlas_min", "forest"}
-DEFAULTS = {"primary_table": 1, "tlas": 1, "tlas_min": 8, "forest": 1, "stack_wide": -1, "tile_feedback_period": 8, "kernel_variant": -1, "lds_scene": 1, "tile_feedback": 1, "cull_roots": -1, "pixel_cache": 1, "vote_eighths": 6, "vote_patience": 3}
+DEFAULTS = {"primary_table": 1, "tlas": 1, "tlas_min": 8, "forest": 1, "stack_wide": -1, "tile_feedback_period": 8, "kernel_variant": -1, "lds_scene": 1, "tile_feedback": 1, "cull_roots": -1, "pixel_cache": 1, "vote_eighths": -1, "vote_patience": -1}
 
 
 def main():

@@ -25,7 +25,8 @@ TIMED = {0: "intersect_scene (all)", 1: "sample start (ray gen / memo ray)", 2: 
          4: "root-leaf meshes", 5: "forest: root-box marks", 6: "forest: node visits", 7: "forest: leaf triangles",
          8: "forest: deal tasks, fetch rays", 9: "winner finalize", 10: "miss: sky", 11: "memo hit load",
          12: "shade (hit)", 13: "memo hit store", 14: "refill / tile pull", 15: "path_step (all)",
-         16: "single-mesh BVH walk", 17: "forest: world hit + results back", 18: "two-leaf meshes", 19: "mesh hit -> world, offer"}
+         16: "single-mesh BVH walk", 17: "forest: world hit + results back", 18: "two-leaf meshes", 19: "mesh hit -> world, offer",
+         20: "park: slot + record store", 21: "resume: record load (in refill)", 22: "resume: hit load, offer, finish"}
 
 
 def build_timed():
@@ -61,16 +62,26 @@ def main():
     else:
         arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
     tr = rt.RayTracer(0, W, H)
+    spp, batch = int(os.environ.get("DIAG_SPP", 8)), int(os.environ.get("DIAG_BATCH", 1))
+    for kv in os.environ.get("DIAG_OPTS", "").split(","):
+        if kv:
+            tr.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    if batch > 1:
+        tr.set_option("batch_frames", batch)
     tr.load_scene(arrays)
     tr.set_option("kernel_variant", variant)
     L = rt.load()
     buf = (C.c_uint64 * 64)()
     L.rt_diag_read(tr._h, buf, 1)
-    tr.render(rt.make_params(W, H, 4, 8, skybox=1, frames=0))
+    if batch > 1:
+        tr.render_frames(rt.make_params(W, H, 4, spp, skybox=1, frames=0), batch)
+    else:
+        tr.render(rt.make_params(W, H, 4, spp, skybox=1, frames=0))
     L.rt_diag_read(tr._h, buf, 1)
+    print(tr.last_launch())
     if timed:
         tot = buf[40 + 15] + buf[40 + 14]
-        print(f"variant {variant}: {W}x{H}, 8 spp, 4 bounces -- wave-cycles per section (s_memtime), share of path_step + refill")
+        print(f"variant {variant}: {W}x{H}, {spp} spp x {batch} frames, 4 bounces -- wave-cycles per section (s_memtime), share of path_step + refill")
         for k, name in TIMED.items():
             print(f"{name:36s} {buf[40 + k]:16d} {buf[40 + k] / tot:7.1%}")
         return

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Frame times of every BASELINE config on its stand-in, at the frames-per-launch settings a host would use, written as the
-tracked table profiles/<tag>_standins.txt (HIP-event times around the launches, rt_get_stats; default options).
+tracked table profiles/<tag>_standins.txt (wall time of the whole sequence of launches / frames; default options).
 
     python tools/standins_table.py r03            # on the GPU box; writes gpurun_out/r03_standins.txt (copy to profiles/)
 """
 import os
 import statistics
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -43,9 +44,11 @@ def measure(arrays, w, h, spp, bounces, batch, frames, reps=3, opts=()):
     for r in range(reps):
         tr.synchronize()
         tr.reset_timing()
+        t0 = time.perf_counter()
         run(max(batch, 2) + r * frames, frames)
+        tr.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3 / frames)
         st = tr.stats()
-        ts.append(st.kernel_ms / st.frames)
     info = tr.last_launch()
     rays, reused = st.segments / st.frames, st.segments_reused / st.frames
     tr.close()
@@ -56,8 +59,8 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     out = []
     say = lambda s: (out.append(s), print(s, flush=True))
-    say(f"Stand-in frame times, {tag} (tools/standins_table.py; one MI355X; kernel time per frame from the HIP events around the launches,")
-    say("median of 3 repetitions; default options; [n] = frames per launch, [1] = one rt_render per frame).  The named assets of")
+    say(f"Stand-in frame times, {tag} (tools/standins_table.py; one MI355X; wall time per frame of back-to-back launches, rt_synchronize at the end,")
+    say("median of 3 repetitions; default options; [n] = frames per launch, [1] = one rt_render per frame, consecutive frames pipelined).  The named assets of")
     say("BASELINE configs 3-5 are absent from the reference checkout (.MISSING_LARGE_BLOBS): these are the stand-ins of SURVEY.md 8(d).")
     say("")
     cases = [
