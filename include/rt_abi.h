@@ -325,6 +325,8 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 for that many rounds; -1: by the work of the launch and the mesh's size,
  *                                                 and only while both park queues fit a quarter of the free memory
  *   defer_min_nodes       >= 1 (1024) (upload)    smallest BVH (internal nodes) whose mesh may be the deferred one
+ *   fast_miss             0 / 1 (1)               a memoised primary ray that leaves the scene ends its pixel in one step: the
+ *                                                 remaining samples are that segment again and their light is added in order
  *   park_levels           0 / 1 (1)               a parking launch runs the deferred walk's first two levels inline and parks
  *                                                 only the rays that reach a grandchild box (0: every ray that can hit the root box)
  *   hybrid                0 / 1 (0)               the parking launches of a deferred-walk sequence stage everything but the big

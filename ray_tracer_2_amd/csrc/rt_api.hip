@@ -136,6 +136,7 @@ struct rt_handle {
     // two workgroups per CU, 10.64 -> 13.47 ms; the 42 top records that fit at full occupancy make every tree fetch a
     // two-path load, 10.67 -> 11.98 ms)
     int lds_tlas = 0;
+    int fast_miss = 1;  // option "fast_miss"
     int park_levels = 1;  // option "park_levels": the parking launches run the deferred walk's first two levels inline
     uint32_t n_tlas_records = 0;
     float4* own_image = nullptr;  // allocated by rt_create; `image` may be rebound
@@ -1116,6 +1117,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "pipeline") {
         if (value < 0 || value > 3) return fail(h, RT_ERR_INVALID_ARGUMENT, "pipeline must be 0 (off), 2 or 3 (frames in flight)");
         h->pipeline = value == 1 ? 3 : value;
+    } else if (n == "fast_miss") {
+        h->fast_miss = value ? 1 : 0;
     } else if (n == "park_levels") {
         h->park_levels = value ? 1 : 0;
     } else if (n == "hybrid") {
@@ -1298,6 +1301,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         a.pixel_cache = 2;
         a.pixel_cache_mem = h->pixel_cache_mem;
     }
+    a.fast_miss = h->fast_miss != 0 && a.pixel_cache != 0u ? 1u : 0u;
     // how many rounds of deferred walks this launch would run (0: none)
     const size_t park_records = (size_t)need_texels * (n_batch ? n_batch : 1u);
     const size_t park_bytes = ((park_records + 63) / 64) * (size_t)PARK_PLANES * 64u * sizeof(float4);  // per queue
@@ -1690,6 +1694,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
                 ah.pixel_cache_mem = a.pixel_cache_mem;
             }
             if (!ah.pixel_cache) ah.primary = nullptr;
+            ah.fast_miss = h->fast_miss != 0 && ah.pixel_cache != 0u ? 1u : 0u;
             if (render_lds_bytes(ah) > LDS_BUDGET_BYTES) hybrid = false;
             ah.persistent_blocks = h->persistent_blocks;
             ah.park_levels = 0;  // (the small blob has no record of the big mesh's BVH)

@@ -204,6 +204,7 @@ struct RenderArgs {
     // the segment, go on until the next entry into the big mesh.  A pixel's operations and their order are those of
     // the undeferred loop, so the image is the same bit for bit; the last launch of a sequence has park = 0 and
     // walks what is left inline.
+    uint32_t fast_miss;           // != 0: a memoised primary ray that misses ends its pixel in one step (path_end, option "fast_miss")
     uint32_t park;
     uint32_t park_levels;         // != 0: a ray parks only if the walk's first two levels reach a grandchild box (option "park_levels")
     float4* q_in;                 // park records to resume instead of tiles (null: the work items are tiles)

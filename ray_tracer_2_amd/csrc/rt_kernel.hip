@@ -1458,6 +1458,9 @@ DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32
         const uint32_t n_want = (uint32_t)__popcll(__ballot(!reuse_hit));
         const bool run = n_want * 8u >= n_here * a.vote_eighths || starve >= a.vote_patience;
         starve = (n_want != 0u && !run) ? starve + 1u : 0u;
+#if defined(RT_DIAG)
+        if (n_want == 0u) { DIAG(28); } else if (run && n_want == n_here) { DIAG(29); } else if (run) { DIAG(30); } else { DIAG(31); }
+#endif
         if (!reuse_hit && !run) return STEP_WAIT;  // nothing about this lane has changed
     }
     return reuse_hit ? STEP_REUSE : STEP_TRAVERSE;
@@ -1502,11 +1505,16 @@ DEV void memo_hit_store(const RenderArgs& a, const PixelState& s, uint32_t* ls, 
 }
 
 // LDS: material reads from LDS; TOTAL_LDS: the pixel sum lives in the lane's LDS state
-template <bool LDS, bool TOTAL_LDS, bool SIMPLE = false>
+// FAST_MISS (the product's memo-using instantiations): a memoised primary ray that leaves the scene ends the pixel --
+// every remaining sample is this same segment (the same ray, throughput 1, no light yet, the same sky; the draws of
+// its zero-strength jitter are made and never read), so the lane adds the sample's light once per remaining sample
+// right here, in order, instead of coming back for one iteration each; `more_reused` counts those segments.
+template <bool LDS, bool TOTAL_LDS, bool SIMPLE = false, bool FAST_MISS = false>
 DEV bool path_end(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t mode, const Hit& hit,
-                  uint32_t& n_segments) {
+                  uint32_t& n_segments, uint32_t* more_reused = nullptr) {
     const int32_t nb = a.params.number_of_bounces;
     bool end_path = true;
+    uint32_t again = 0u;  // further samples of the pixel that are this sample again
     if (mode != STEP_END) {
         n_segments += 1;
         if ((s.meta & 0xffffu) != 0xffffu) s.meta += 1;
@@ -1514,6 +1522,14 @@ DEV bool path_end(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t mod
             DIAG(12);
             TIC(t10);
             if (a.params.skybox != 0) s.light = s.light + s.T * environment_light(s.rd);
+            if constexpr (FAST_MISS) {
+                if (a.fast_miss != 0u && s.seg == 0) {  // (pixel_cache != 0, wave-uniform)
+                    uint32_t st = 0u;
+                    with_memo(a, ls, [&](auto pc) { st = pc[12 * 64]; });
+                    if ((st & (MEMO_RAY | MEMO_HIT_VALID)) == (MEMO_RAY | MEMO_HIT_VALID))
+                        again = (uint32_t)(a.params.rays_per_pixel - 1 - s.j);
+                }
+            }
             TOC(t10, 10);
         } else {
             TIC(t12);
@@ -1584,14 +1600,26 @@ DEV bool path_end(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t mod
     }
     if (end_path) {  // wgsl:496
         if constexpr (TOTAL_LDS) {
-            ls[0] = __float_as_uint(__uint_as_float(ls[0]) + s.light.x);  // total += incoming_light
-            ls[64] = __float_as_uint(__uint_as_float(ls[64]) + s.light.y);
-            ls[128] = __float_as_uint(__uint_as_float(ls[128]) + s.light.z);
-            ls[192] = __float_as_uint(__uint_as_float(ls[192]) + s.light.w);
+            f4 t{__uint_as_float(ls[0]), __uint_as_float(ls[64]), __uint_as_float(ls[128]), __uint_as_float(ls[192])};
+            t = t + s.light;  // total += incoming_light
+            if constexpr (FAST_MISS)
+                for (uint32_t k = 0; k < again; ++k) t = t + s.light;
+            ls[0] = __float_as_uint(t.x); ls[64] = __float_as_uint(t.y); ls[128] = __float_as_uint(t.z); ls[192] = __float_as_uint(t.w);
         } else {
             s.total = s.total + s.light;
+            if constexpr (FAST_MISS)
+                for (uint32_t k = 0; k < again; ++k) s.total = s.total + s.light;
         }
         s.j += 1;
+        if constexpr (FAST_MISS) {
+            if (again != 0u) {
+                s.j += (int32_t)again;
+                n_segments += again;
+                *more_reused += again;
+                const uint32_t rays = (s.meta & 0xffffu) + again;
+                s.meta = (s.meta & 0xffff0000u) | (rays < 0xffffu ? rays : 0xffffu);
+            }
+        }
         s.fresh = true;
         return s.j >= a.params.rays_per_pixel;
     }
@@ -1607,7 +1635,7 @@ DEV void park_load_hit(const RenderArgs& a, uint32_t slot, Isect& I, CompactHit&
 
 template <bool LDS, bool STATS, bool TLAS, bool PARK = false, bool SIMPLE = false, bool HYB = false>
 DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
-                       bool& reused, int& node_tests, int& tri_tests, uint32_t resume_slot = 0xffffffffu) {
+                       bool& reused, uint32_t& more_reused, int& node_tests, int& tri_tests, uint32_t resume_slot = 0xffffffffu) {
     // (a resumed pixel was parked behind path_begin: its segment has begun)
     const uint32_t mode = PARK && resume_slot != 0xffffffffu ? (uint32_t)STEP_RESUME : path_begin<STATS, SIMPLE>(a, s, ls, starve);
     // segments served from the memo: the caller counts them per wave, OUTSIDE its `if (active)` (a ballot + a scalar
@@ -1667,7 +1695,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
         memo_hit_store<STATS>(a, s, ls, hit);
         TOC(t22, 22);
     }
-    return path_end<LDS, total_in_lds(LDS), SIMPLE>(a, s, ls, mode, hit, n_segments) ? PATH_PIXEL_DONE : PATH_CONTINUE;
+    return path_end<LDS, total_in_lds(LDS), SIMPLE, !STATS>(a, s, ls, mode, hit, n_segments, &more_reused) ? PATH_PIXEL_DONE : PATH_CONTINUE;
 }
 
 // Park records (rt_device.h): the whole state of a pixel between two segments.
@@ -1786,9 +1814,11 @@ DEV void tile_cost_add(const RenderArgs& a, uint32_t* tbl, const PixelState& s) 
 }
 
 template <bool STATS>
-DEV void flush_counters(const RenderArgs& a, uint32_t n_segments, uint32_t n_reused_wave, int node_tests, int tri_tests) {
+DEV void flush_counters(const RenderArgs& a, uint32_t n_segments, uint32_t n_reused_wave, int node_tests, int tri_tests,
+                        uint32_t more_reused = 0u) {
     if (a.counters && __ballot(n_segments != 0u || (STATS && (node_tests | tri_tests) != 0)) != 0ull) {
         atomicAdd(&a.counters->segments, (unsigned long long)n_segments);
+        if (more_reused != 0u) atomicAdd(&a.counters->reused, (unsigned long long)more_reused);  // (per lane)
         // (n_reused_wave is the same in every lane: accumulated from ballots taken with the whole wave present)
         if (n_reused_wave != 0u && (threadIdx.x & 63u) == 0u) atomicAdd(&a.counters->reused, (unsigned long long)n_reused_wave);
         if (STATS) {
@@ -1816,11 +1846,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     pixel_cache_begin(a, a, cam, s, ls);
     uint32_t starve = 0;
     bool active = valid && a.params.rays_per_pixel > 0;
-    uint32_t n_segments = 0, n_reused_wave = 0;
+    uint32_t n_segments = 0, n_reused_wave = 0, more_reused = 0;  // (more_reused: per lane, path_end's FAST_MISS)
     int node_tests = 0, tri_tests = 0;
     while (__ballot(active) != 0ull) {
         bool reused = false;
-        if (active && path_step<LDS, STATS, TLAS, false, SIMPLE>(a, s, ls, starve, n_segments, reused, node_tests, tri_tests) == PATH_PIXEL_DONE)
+        if (active && path_step<LDS, STATS, TLAS, false, SIMPLE>(a, s, ls, starve, n_segments, reused, more_reused, node_tests, tri_tests) == PATH_PIXEL_DONE)
             active = false;
         n_reused_wave += (uint32_t)__popcll(__ballot(reused));  // (wave-uniform: every lane is here)
     }
@@ -1830,7 +1860,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
         for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
         if ((threadIdx.x & 63u) == 0u) a.tile_cost[tile] = sum;
     }
-    flush_counters<STATS>(a, n_segments, n_reused_wave, node_tests, tri_tests);
+    flush_counters<STATS>(a, n_segments, n_reused_wave, node_tests, tri_tests, more_reused);
 }
 
 // Variant 0 (default): persistent waves with active-lane refill.  Each wave
@@ -1865,7 +1895,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
     PixelState s;
     pixel_begin<total_in_lds(LDS)>(a, camera_consts(a), s, ls, 0, 0, 0);
     bool active = false;
-    uint32_t n_segments = 0, n_reused_wave = 0;
+    uint32_t n_segments = 0, n_reused_wave = 0, more_reused = 0;  // (more_reused: per lane, path_end's FAST_MISS)
     int node_tests = 0, tri_tests = 0;
     // this wave's tile-cost table sits behind the workgroup's traversal stacks
     uint32_t* cost_tbl = cost_table_of_wave<LDS>(a);
@@ -1955,7 +1985,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         uint32_t step = PATH_CONTINUE;
         bool reused = false;
         if (active) {
-            step = path_step<LDS, STATS, TLAS, PARK, SIMPLE, HYB>(a, s, ls, starve, n_segments, reused, node_tests, tri_tests, resume_slot);
+            step = path_step<LDS, STATS, TLAS, PARK, SIMPLE, HYB>(a, s, ls, starve, n_segments, reused, more_reused, node_tests, tri_tests, resume_slot);
             resume_slot = 0xffffffffu;
             if (step == PATH_PIXEL_DONE) {
                 DIAG(16);
@@ -1968,7 +1998,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         n_reused_wave += (uint32_t)__popcll(__ballot(reused));  // (wave-uniform: every lane is here)
         TOC(t15, 15);
     }
-    flush_counters<STATS>(a, n_segments, n_reused_wave, node_tests, tri_tests);
+    flush_counters<STATS>(a, n_segments, n_reused_wave, node_tests, tri_tests, more_reused);
 #if defined(RT_DIAGT)
     if (lane < 24u) atomicAdd(&g_diag[40 + lane], g_tacc[threadIdx.x >> 6][lane]);
 #endif

@@ -17,7 +17,7 @@ SECTIONS = {0: "iteration (path_step)", 1: "sample start (ray gen)", 3: "mesh tr
             4: "root-leaf tri: det", 5: "root-leaf tri: body", 6: "bvh: node visit", 7: "bvh: internal (2 aabb)",
             8: "bvh-leaf tri: det", 9: "bvh-leaf tri: body", 10: "mesh hit -> world", 11: "winner finalize",
             12: "miss: sky", 13: "shade: diffuse", 14: "shade: glass", 15: "refill: pixel_begin",
-            16: "pixel_finish", 17: "top tree: node (2 aabb)", 18: "top tree: mesh entry", 19: "shared walk: loop trip"}
+            16: "pixel_finish", 28: "vote: nobody wants", 29: "vote: run, all want", 30: "vote: run, some reuse", 31: "vote: wait", 17: "top tree: node (2 aabb)", 18: "top tree: mesh entry", 19: "shared walk: loop trip"}
 
 
 TIME_SO = os.path.join(ROOT, "ray_tracer_2_amd", "librt2_mi355x_diagt.so")
