@@ -1706,21 +1706,26 @@ DEV void park_store(const RenderArgs& a, uint32_t slot, const PixelState& s, uin
     f4 total = s.total;
     if constexpr (TOTAL_LDS)
         total = f4{__uint_as_float(ls[0]), __uint_as_float(ls[64]), __uint_as_float(ls[128]), __uint_as_float(ls[192])};
-    uint32_t m[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // (the memo's 13 dwords as named values: an indexed local array kept its 52 bytes of scratch frame)
+    float4 m0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), m1 = m0, m2 = m0;
+    uint32_t m12 = 0u;
     if (a.pixel_cache != 0u)
         with_memo(a, ls, [&](auto pc) {
-            for (uint32_t k = 0; k < 13u; ++k) m[k] = pc[k * 64u];
+            m0 = make_float4(u(pc[0 * 64]), u(pc[1 * 64]), u(pc[2 * 64]), u(pc[3 * 64]));
+            m1 = make_float4(u(pc[4 * 64]), u(pc[5 * 64]), u(pc[6 * 64]), u(pc[7 * 64]));
+            m2 = make_float4(u(pc[8 * 64]), u(pc[9 * 64]), u(pc[10 * 64]), u(pc[11 * 64]));
+            m12 = pc[12 * 64];
         });
     q[0 * 64] = make_float4(u(s.x), u(s.out_row), u(s.rng), u((uint32_t)s.j));
-    q[1 * 64] = make_float4(u((uint32_t)s.seg), u(s.fresh ? 1u : 0u), u(s.meta), u(m[12]));
+    q[1 * 64] = make_float4(u((uint32_t)s.seg), u(s.fresh ? 1u : 0u), u(s.meta), u(m12));
     q[2 * 64] = make_float4(s.ro.x, s.ro.y, s.ro.z, s.rd.x);
     q[3 * 64] = make_float4(s.rd.y, s.rd.z, s.T.x, s.T.y);
     q[4 * 64] = make_float4(s.T.z, s.T.w, s.light.x, s.light.y);
     q[5 * 64] = make_float4(s.light.z, s.light.w, 0.0f, 0.0f);
     q[6 * 64] = make_float4(total.x, total.y, total.z, total.w);
-    q[7 * 64] = make_float4(u(m[0]), u(m[1]), u(m[2]), u(m[3]));
-    q[8 * 64] = make_float4(u(m[4]), u(m[5]), u(m[6]), u(m[7]));
-    q[9 * 64] = make_float4(u(m[8]), u(m[9]), u(m[10]), u(m[11]));
+    q[7 * 64] = m0;
+    q[8 * 64] = m1;
+    q[9 * 64] = m2;
     q[10 * 64] = make_float4(I.closest, u((uint32_t)I.object), u((I.any ? 1u : 0u) | (I.s_inside ? 2u : 0u)), I.s_dst);
     q[11 * 64] = make_float4(I.win_u, I.win_v, u(I.win_tri), I.win_point.x);
     q[12 * 64] = make_float4(I.win_point.y, I.win_point.z, 0.0f, 0.0f);
