@@ -91,26 +91,11 @@ RT_HD LogRed log_reduce(float x) {
     return r;
 }
 
-// log(1+f) - f + f*f/2 == s*(hfsq + R), msun polynomial
-RT_HD float log1p_kernel(float f, float* hfsq_out) {
-    const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f, Lg3 = 0.28498786688f,
-                Lg4 = 0.24279078841f;
-    float s = f / (2.0f + f);
-    float z = s * s;
-    float w = z * z;
-    float t1 = w * (Lg2 + w * Lg4);
-    float t2 = z * (Lg1 + w * Lg3);
-    float R = t2 + t1;
-    float hfsq = (0.5f * f) * f;
-    *hfsq_out = hfsq;
-    return s * (hfsq + R);
-}
-
 // log(x) = k ln2 + log(1 + f), log(1 + f) = f - f^2/2 + f^3 P(f) with P of degree 7 (near-minimax for the relative
 // error on [sqrt(1/2) - 1, sqrt(2) - 1], fit error 0.1 ULP: tools/micro/fit_transc.py), Horner with explicit fma.
 // Round 3: replaces the msun form above (a correctly rounded division plus 11 unfused operations) -- Box-Muller
 // (wgsl:181-185) takes a logarithm per normal deviate, three per bounce.  <= 1 ULP on rand()'s outputs
-// (tests/test_transc.py).  log2_ / pow_ keep the split-precision msun kernel.
+// (tests/test_transc.py).
 RT_HD float log_(float x) {
     uint32_t ux = f2u(x);
     if ((ux & 0x7fffffffu) == 0) return u2f(0xff800000u);  // log(+-0) = -inf
@@ -139,6 +124,11 @@ RT_HD float log_(float x) {
     return fma_(dk, ln2_hi, y + f);
 }
 
+// log2(x) = k + log(1 + f) / ln2 with log_'s polynomial: log(1 + f) = f + t, t = f^3 P(f) - f^2/2; the product
+// f / ln2 is formed exactly (a + e with one fma) and 1/ln2 carried as hi + lo, so the sum keeps ~30 bits before the
+// final rounding -- pow(x, 500) in the sky's sun term multiplies this error by 500.  Round 3: replaces the msun
+// split-precision form (a correctly rounded division and 25 unfused operations) within the same bound: <= 1 ULP
+// (tests/test_transc.py).
 RT_HD float log2_(float x) {
     uint32_t ux = f2u(x);
     if ((ux & 0x7fffffffu) == 0) return u2f(0xff800000u);
@@ -147,17 +137,27 @@ RT_HD float log2_(float x) {
         if (ux > 0xff800000u || (ux > 0x7f800000u && ux < 0x80000000u)) return x + x;
         return u2f(0x7fc00000u);
     }
-    // log2(x) = k + log(1+f)/ln2, with log(1+f) split into hi + lo so the
-    // product with 1/ln2 keeps ~30 bits.
-    const float ivln2hi = 1.4428710938e+00f, ivln2lo = -1.7605285393e-04f;
+    const float ivln2 = 1.4426950216293335f, ivln2_lo = 1.925963033500011e-08f;
+    const float P0 = 0.3333333134651184f, P1 = -0.250008225440979f, P2 = 0.20001231133937836f,
+                P3 = -0.16623249650001526f, P4 = 0.14201568067073822f, P5 = -0.13161104917526245f,
+                P6 = 0.12763474881649017f, P7 = -0.07634374499320984f;
     LogRed r = log_reduce(x);
-    float hfsq;
-    float sr = log1p_kernel(r.f, &hfsq);
-    float hi = r.f - hfsq;
-    hi = u2f(f2u(hi) & 0xfffff000u);
-    float lo = ((r.f - hi) - hfsq) + sr;
-    float dk = (float)r.k;
-    return (((lo + hi) * ivln2lo + lo * ivln2hi) + hi * ivln2hi) + dk;
+    const float f = r.f, z = f * f, dk = (float)r.k;
+    float p = fma_(P7, f, P6);
+    p = fma_(p, f, P5);
+    p = fma_(p, f, P4);
+    p = fma_(p, f, P3);
+    p = fma_(p, f, P2);
+    p = fma_(p, f, P1);
+    p = fma_(p, f, P0);
+    float t = (f * z) * p;
+    t = fma_(-0.5f, z, t);              // log(1 + f) - f
+    const float a = f * ivln2;
+    const float e = fma_(f, ivln2, -a);  // f * ivln2 == a + e exactly
+    const float lo = fma_(t, ivln2, fma_(f, ivln2_lo, e));
+    const float hi = dk + a;
+    const float he = a - (hi - dk);      // (exact: |dk| >= 1 > |a| or dk == 0)
+    return hi + (lo + he);
 }
 
 // --------------------------------------------------------------- exp2 ----
