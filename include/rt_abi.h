@@ -350,9 +350,13 @@ void* rt_stream(rt_handle* h);
  * host arrays of n floats (bit patterns for integer inputs/outputs).  fn: 0 log, 1 cos, 2 sin, 3 exp,
  * 4 exp2, 5 log2, 6 pow(x,y), 7 acos, 8 atan2(x,y), 9 sqrt, 10 x/y, 11 rand() from RNG state bits x,
  * 12 next_random_number of state x (bits), 13 trig_signbits(x) (bits), 14 rand_normal_dist() from
- * state x, 15 f32(u32 bits x) * 2^-32, 16 normalize(x, y, x*y).x.  The second call filters one RGBA8 sRGB
- * texture at n (u, v) pairs (wgsl:455 as csrc/rt_texture.h defines it). */
+ * state x, 15 f32(u32 bits x) * 2^-32, 16 normalize(x, y, x*y).x, 17 the kernels' reciprocal rcp_(x), 18 their
+ * sqrt_dev(x).  The second call filters one RGBA8 sRGB texture at n (u, v) pairs (wgsl:455 as csrc/rt_texture.h defines
+ * it).  The third compares the kernels' short reciprocal (which = 0) / square root (which = 1) with the compiler's IEEE
+ * 1.0f / x / sqrt on the device for EVERY float in the range the short form serves: out3 = {floats checked,
+ * mismatches, a mismatching bit pattern}. */
 int rt_test_device_units(rt_handle* h, int fn, const float* x, const float* y, float* out, uint64_t n);
+int rt_test_sweep(rt_handle* h, int which, uint64_t* out3);
 int rt_test_device_sample_texture(rt_handle* h, const rt_texture_desc* tex, const float* uv, float* rgba_out,
                                   uint64_t n);
 

@@ -35,6 +35,7 @@ hipError_t launch_wf_shade(const RenderArgs& a, uint32_t blocks, hipStream_t str
 hipError_t launch_wf_walk(const RenderArgs& a, uint32_t blocks, hipStream_t stream);
 size_t wf_walk_lds_bytes(const RenderArgs& a);
 hipError_t launch_units(int fn, const float* x, const float* y, float* out, unsigned long long n, hipStream_t stream);
+hipError_t launch_sweep(int which, unsigned long long* out, hipStream_t stream);
 hipError_t launch_units_texture(const uint8_t* rgba8, uint32_t width, uint32_t height, const float* srgb_lut, const float* uv,
                                 float* out, unsigned long long n, hipStream_t stream);
 hipError_t launch_assemble(const float4* gathered, float4* image, uint32_t width, uint32_t height,
@@ -2126,6 +2127,19 @@ int rt_test_device_units(rt_handle* h, int fn, const float* x, const float* y, f
     free_dev(dx);
     free_dev(dy);
     free_dev(dout);
+    return RT_OK;
+}
+
+int rt_test_sweep(rt_handle* h, int which, uint64_t* out3) {
+    if (!h || !out3 || which < 0 || which > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&d, 3 * sizeof(unsigned long long)));
+    HIP_TRY(h, hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, launch_sweep(which, d, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out3, d, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_dev(d);
     return RT_OK;
 }
 

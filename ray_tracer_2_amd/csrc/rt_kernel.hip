@@ -107,11 +107,53 @@ DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 DEV f3 cross3(f3 a, f3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
+// 1.0f / x, correctly rounded, in fewer instructions than the compiler's IEEE division (11: two v_div_scale, v_rcp, six
+// fma, v_div_fmas, v_div_fixup).  For a normal x whose reciprocal is normal and away from the denormals, v_rcp_f32
+// (1 ULP) plus one Newton step in fma arithmetic lands on the correctly rounded quotient -- not by argument but by
+// enumeration: rt_sweep_kernel compares the two for EVERY float in that range on the device
+// (tests/test_gpu_device_units.py::test_rcp_is_the_ieee_division_for_every_float).  If a lane of the wave holds anything
+// else (zero, denormal, huge, inf, NaN), the whole wave takes the compiler's division.
+DEV bool rcp_in_range(float x) { return rtm::abs_(x) >= 0x1p-120f && rtm::abs_(x) <= 0x1p+120f; }  // (false for NaN)
+DEV float rcp_core(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return rtm::fma_(r, rtm::fma_(-x, r, 1.0f), r);
+}
+DEV float rcp_(float x) {
+#if defined(RT_IEEE_DIV)
+    return 1.0f / x;
+#else
+    if (__ballot(!rcp_in_range(x)) != 0ull) return 1.0f / x;
+    return rcp_core(x);
+#endif
+}
+// sqrt(x), correctly rounded: the compiler's own expansion (v_sqrt_f32, then the two neighbours tried with an exact fma
+// residual) without its scaling for denormal inputs and its class check -- for a normal positive x away from both
+// ends; enumerated against __builtin_sqrtf on the device like rcp_.  The compiler's expansion for the whole wave otherwise.
+DEV bool sqrt_in_range(float x) { return x >= 0x1p-100f && x <= 0x1p+100f; }  // (false for NaN, zero, negatives)
+DEV float sqrt_core(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rb = rtm::fma_(-below, s, x), ra = rtm::fma_(-above, s, x);
+    float r = 0.0f >= rb ? below : s;
+    r = 0.0f < ra ? above : r;
+    return r;
+}
+DEV float sqrt_dev(float x) {
+#if defined(RT_IEEE_DIV)
+    return rtm::sqrt_(x);
+#else
+    if (__ballot(!sqrt_in_range(x)) != 0ull) return rtm::sqrt_(x);
+    return sqrt_core(x);
+#endif
+}
 // WGSL leaves normalize()'s precision to the implementation ("inherited from e / length(e)", with 2.5 ULP for a
 // division); drivers multiply by an inverse square root.  Canonical here (round 3): ONE correctly rounded reciprocal
 // of the correctly rounded length, then three multiplications -- 19 instructions fewer than three IEEE divisions,
 // five or so times per segment.  The oracle's normalize() is the same two-step form.
-DEV f3 normalize3(f3 a) { return a * (1.0f / rtm::sqrt_(dot3(a, a))); }
+// (SQ: the short square root too.  Measured per kernel family -- tools/experiments/README.md: it is worth 1.5 % to the
+// kernels that read the scene from global memory and costs the LDS-scene kernels 0.7 %, so the callers pass !LDS.)
+template <bool SQ = false>
+DEV f3 normalize3(f3 a) { return a * rcp_(SQ ? sqrt_dev(dot3(a, a)) : rtm::sqrt_(dot3(a, a))); }
 DEV f3 mix3(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }
 DEV f4 mix4(f4 a, f4 b, float t) { return a * (1.0f - t) + b * t; }
 DEV f3 reflect3(f3 I, f3 N) { return I - (2.0f * dot3(N, I)) * N; }
@@ -150,11 +192,12 @@ DEV float rand_normal_dist(uint32_t& s) {
     float rho = rtm::sqrt_(-2.0f * rtm::log_(rand_(s)));
     return rho * rtm::cos_(theta);
 }
+template <bool SQ = false>
 DEV f3 rand_unit_sphere(uint32_t& s) {
     float x = rand_normal_dist(s);
     float y = rand_normal_dist(s);
     float z = rand_normal_dist(s);
-    return normalize3(f3{x, y, z});
+    return normalize3<SQ>(f3{x, y, z});
 }
 DEV void rand_in_unit_disk(uint32_t& s, float& ox, float& oy) {
     float angle = (rand_(s) * 2.0f) * 3.1415926f;
@@ -283,7 +326,7 @@ DEV void tri_test(f3 lo, f3 ld, float4 q0, float4 q1, float4 q2, bool cull, uint
         f3 eab{q1.x, q1.y, q1.z}, eac{q2.x, q2.y, q2.z};
         f3 ao = lo - v1;
         f3 dao = cross3(ao, ld);
-        float inv = 1.0f / det;
+        float inv = rcp_(det);
         float dst = dot3(ao, n) * inv;
         float u = dot3(eac, dao) * inv;
         float v = -dot3(eab, dao) * inv;
@@ -703,10 +746,10 @@ DEV Hit isect_finish(const RenderArgs& a, const Isect& I, f3 ro, f3 rd) {
                 s0 = ld4<LDS>(a, so); s1 = ld4<LDS>(a, so + 16); s2 = ld4<LDS>(a, so + 32); s3 = ld4<LDS>(a, so + 48);
             }
             f3 n1{s0.x, s0.y, s0.z}, n2{s1.x, s1.y, s1.z}, n3{s2.x, s2.y, s2.z};
-            f3 ln = normalize3((n1 * ww + n2 * wu) + n3 * wv) * (det_negative ? -1.0f : 1.0f);
+            f3 ln = normalize3<!LDS>((n1 * ww + n2 * wu) + n3 * wv) * (det_negative ? -1.0f : 1.0f);
             const float4 c0 = ld4<LDS>(a, mo + 64), c1 = ld4<LDS>(a, mo + 80), c2 = ld4<LDS>(a, mo + 96),
                          c3 = ld4<LDS>(a, mo + 112);
-            h.normal = normalize3(mat_cols_xyz(c0, c1, c2, c3, ln, 0.0f));
+            h.normal = normalize3<!LDS>(mat_cols_xyz(c0, c1, c2, c3, ln, 0.0f));
             h.backface = det_negative;
             h.point = I.win_point;
             // uv = (uv1 * w + uv2 * u) + uv3 * v, uv1 = (u10,u11), uv2 = (u20,u21), uv3 = (u30,u31)
@@ -718,7 +761,7 @@ DEV Hit isect_finish(const RenderArgs& a, const Isect& I, f3 ro, f3 rd) {
             const float4 sp = ld4<LDS>(a, a.lay.sphere_off + si * SPHERE_BYTES);
             f3 c{sp.x, sp.y, sp.z};
             h.point = ro + rd * I.s_dst;
-            f3 n = normalize3(h.point - c);
+            f3 n = normalize3<!LDS>(h.point - c);
             h.normal = I.s_inside ? -n : n;
             h.backface = I.s_inside;
             const float pi = 3.1415926f;
@@ -828,8 +871,8 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             const float4 c0 = ld4<LDS>(a, xo), c1 = ld4<LDS>(a, xo + 16), c2 = ld4<LDS>(a, xo + 32),
                          c3 = ld4<LDS>(a, xo + 48);
             lo = mat_cols_xyz(c0, c1, c2, c3, ro, 1.0f);
-            ld = normalize3(mat_cols_xyz(c0, c1, c2, c3, rd, 0.0f));
-            inv = f3{1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z};
+            ld = normalize3<!LDS>(mat_cols_xyz(c0, c1, c2, c3, rd, 0.0f));
+            inv = f3{rcp_(ld.x), rcp_(ld.y), rcp_(ld.z)};
             // the root-box arguments below are only proven for finite slab arithmetic
             if constexpr (TLAS)
                 cull_ok = rtm::abs_(inv.x) < INF && rtm::abs_(inv.y) < INF && rtm::abs_(inv.z) < INF &&
@@ -1339,7 +1382,7 @@ DEV size_t primary_index(uint32_t width, uint32_t x, uint32_t y) {
 }
 
 // the memoised primary ray of pixel (x, y): direction, and whether the ray is constant at all
-template <class A>
+template <bool SQ = false, class A>
 DEV f3 memo_ray_of(const A& ca, const CameraConsts& c, uint32_t x, uint32_t y, bool& constant_ray) {
     const f3 focus = focus_point_of(ca, c, x, y);
     auto not_neg_zero = [](float v) { return __float_as_uint(v) != 0x80000000u; };
@@ -1355,13 +1398,13 @@ DEV f3 memo_ray_of(const A& ca, const CameraConsts& c, uint32_t x, uint32_t y, b
         // with these same operations)
         const f3 ro = (c.origin + c.right * 0.0f) + c.up * 0.0f;
         const f3 jfp = (focus + c.right * 0.0f) + c.up * 0.0f;
-        rd = normalize3(jfp - ro);
-        rd = normalize3(rd);  // wgsl:400
+        rd = normalize3<SQ>(jfp - ro);
+        rd = normalize3<SQ>(rd);  // wgsl:400
     }
     return rd;
 }
 
-template <bool WF = false, class A>
+template <bool WF = false, bool SQ = false, class A>
 DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts& c, const PixelState& s, uint32_t* ls) {
     if (!a.pixel_cache) return;
     bool constant_ray;
@@ -1379,7 +1422,7 @@ DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts&
         rd = f3{v[0], v[1], v[2]};
         constant_ray = rd.x == rd.x;
     } else {
-        rd = memo_ray_of(ca, c, s.x, y, constant_ray);
+        rd = memo_ray_of<SQ>(ca, c, s.x, y, constant_ray);
     }
     with_memo<WF>(a, ls, [&](auto pc) {
         pc[0] = __float_as_uint(rd.x); pc[64] = __float_as_uint(rd.y); pc[128] = __float_as_uint(rd.z);
@@ -1398,7 +1441,7 @@ enum : uint32_t {
     STEP_RESUME = 4,    // deferred walks: the segment's hit is the parked closest-hit record + the big mesh's walk
 };
 
-template <bool STATS, bool SIMPLE = false, bool WF = false>
+template <bool STATS, bool SIMPLE = false, bool WF = false, bool SQ = false>
 DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve) {
     const int32_t nb = a.params.number_of_bounces;
     // Primary-ray memo.  With defocus_strength = diverge_strength = +0 (the default camera) the
@@ -1437,8 +1480,8 @@ DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32
             s.ro = (c.origin + c.right * jx) + c.up * jy;
             const f3 focus = focus_point_of(ca, c, s.x, frame_row_of(ca, s.out_row));
             f3 jfp = (focus + c.right * kx) + c.up * ky;
-            s.rd = normalize3(jfp - s.ro);
-            s.rd = normalize3(s.rd);  // wgsl:400
+            s.rd = normalize3<SQ>(jfp - s.ro);
+            s.rd = normalize3<SQ>(s.rd);  // wgsl:400
         }
         s.T = f4{1, 1, 1, 1};
         s.light = f4{0, 0, 0, 0};
@@ -1557,22 +1600,22 @@ DEV bool path_end(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t mod
                 bool cannot_refract = ior * sin_theta > 1.0f;
                 bool follow_reflection = cannot_refract;
                 if (!cannot_refract) follow_reflection = reflectance(cos_theta, ior) > rand_(s.rng);
-                f3 diffuse_dir = normalize3(hit.normal + rand_unit_sphere(s.rng));
-                reflect_dir = normalize3(mix3(diffuse_dir, reflect_dir, ldf<LDS>(a, mo + M_SPECULAR)));
-                refract_dir = normalize3(mix3(-diffuse_dir, refract_dir, ldf<LDS>(a, mo + M_SMOOTH)));
+                f3 diffuse_dir = normalize3<!LDS>(hit.normal + rand_unit_sphere<!LDS>(s.rng));
+                reflect_dir = normalize3<!LDS>(mix3(diffuse_dir, reflect_dir, ldf<LDS>(a, mo + M_SPECULAR)));
+                refract_dir = normalize3<!LDS>(mix3(-diffuse_dir, refract_dir, ldf<LDS>(a, mo + M_SMOOTH)));
                 rd = follow_reflection ? reflect_dir : refract_dir;
                 s.ro = hit.point + (1e-4f * hit.normal) * sign_(dot3(hit.normal, rd));
             } else {  // wgsl:437-460
                 DIAG(13);
                 const float4 msc = ld4<LDS>(a, mo + M_ABSORB_S);  // (absorb_s, emission_s, smoothness, specular)
                 bool is_spec = msc.w >= rand_(s.rng);
-                f3 sph = rand_unit_sphere(s.rng);
+                f3 sph = rand_unit_sphere<!LDS>(s.rng);
                 f3 diffuse_dir = sph * sign_(dot3(hit.normal, sph));
                 f3 specular_dir = reflect3(rd, hit.normal);
                 const float4 ec = ld4<LDS>(a, mo + M_EMISSION);
                 float es = msc.y;
                 f4 emitted{ec.x * es, ec.y * es, ec.z * es, ec.w * es};
-                rd = normalize3(mix3(diffuse_dir, specular_dir, msc.z * (is_spec ? 1.0f : 0.0f)));
+                rd = normalize3<!LDS>(mix3(diffuse_dir, specular_dir, msc.z * (is_spec ? 1.0f : 0.0f)));
                 s.light = s.light + emitted * T;
                 f4 color;
                 const int diffuse_index = ldi<LDS>(a, mo + M_DIFFUSE_IDX);
@@ -1590,7 +1633,7 @@ DEV bool path_end(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t mod
             float p = max_(T.x, max_(T.y, T.z));  // wgsl:462-466
             bool die = rand_(s.rng) >= p;
             if (!die) {
-                T = T * (1.0f / p);
+                T = T * rcp_(p);
                 s.seg += 1;
                 end_path = s.seg > nb;
             }
@@ -1637,7 +1680,7 @@ template <bool LDS, bool STATS, bool TLAS, bool PARK = false, bool SIMPLE = fals
 DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
                        bool& reused, uint32_t& more_reused, int& node_tests, int& tri_tests, uint32_t resume_slot = 0xffffffffu) {
     // (a resumed pixel was parked behind path_begin: its segment has begun)
-    const uint32_t mode = PARK && resume_slot != 0xffffffffu ? (uint32_t)STEP_RESUME : path_begin<STATS, SIMPLE>(a, s, ls, starve);
+    const uint32_t mode = PARK && resume_slot != 0xffffffffu ? (uint32_t)STEP_RESUME : path_begin<STATS, SIMPLE, false, !LDS>(a, s, ls, starve);
     // segments served from the memo: the caller counts them per wave, OUTSIDE its `if (active)` (a ballot + a scalar
     // add with every lane of the wave present -- counted in here, under the divergent branch, the sum lived in the
     // active lanes only and was lost for every iteration lane 0 sat out)
@@ -1685,7 +1728,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
             const uint32_t xo = a.lay.mesh_off + a.defer_xform * MESH_REC_BYTES;
             const float4 c0 = ld4<LDS>(a, xo), c1 = ld4<LDS>(a, xo + 16), c2 = ld4<LDS>(a, xo + 32), c3 = ld4<LDS>(a, xo + 48);
             const f3 lo = mat_cols_xyz(c0, c1, c2, c3, s.ro, 1.0f);
-            const f3 ld = normalize3(mat_cols_xyz(c0, c1, c2, c3, s.rd, 0.0f));
+            const f3 ld = normalize3<!LDS>(mat_cols_xyz(c0, c1, c2, c3, s.rd, 0.0f));
             f3 whp;
             float wdst;
             world_hit<LDS>(a, a.lay.mesh_off + a.defer_mesh * MESH_REC_BYTES + 64u, lo, ld, s.ro, walked.t, whp, wdst);
@@ -1848,7 +1891,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     const bool valid = tile_ok && px.valid;
     PixelState s;
     pixel_begin<total_in_lds(LDS)>(a, cam, s, ls, px.x, px.y, px.out_row);
-    pixel_cache_begin(a, a, cam, s, ls);
+    pixel_cache_begin<false, !LDS>(a, a, cam, s, ls);
     uint32_t starve = 0;
     bool active = valid && a.params.rays_per_pixel > 0;
     uint32_t n_segments = 0, n_reused_wave = 0, more_reused = 0;  // (more_reused: per lane, path_end's FAST_MISS)
@@ -1965,7 +2008,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
                         DIAG(15);
                         const CameraConsts cam = camera_consts(ca);
                         pixel_begin<total_in_lds(LDS)>(ca, cam, s, ls, px.x, px.y, px.out_row, pool_frame);
-                        pixel_cache_begin(a, ca, cam, s, ls);
+                        pixel_cache_begin<false, !LDS>(a, ca, cam, s, ls);
                         s.meta = ((pull_seq & (COST_SLOTS - 1u)) << 16) | (pool_frame << 19);
                         if (have_samples) {
                             active = true;
@@ -2069,8 +2112,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderA
                     const float4* q = a.q_in + (size_t)(slot >> 6) * (PARK_PLANES * 64u) + (slot & 63u);
                     const float4 p2 = q[2 * 64], p3 = q[3 * 64];
                     lo = mat_cols_xyz(c0, c1, c2, c3, f3{p2.x, p2.y, p2.z}, 1.0f);
-                    ld = normalize3(mat_cols_xyz(c0, c1, c2, c3, f3{p2.w, p3.x, p3.y}, 0.0f));
-                    inv = f3{1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z};
+                    ld = normalize3<true>(mat_cols_xyz(c0, c1, c2, c3, f3{p2.w, p3.x, p3.y}, 0.0f));
+                    inv = f3{rcp_(ld.x), rcp_(ld.y), rcp_(ld.z)};
                     cur = root;
                     cur_count = 0;
                     sp = 0;
@@ -2534,7 +2577,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_wf_walk_kernel
                             const float4 c0 = ld4<false>(a, xo), c1 = ld4<false>(a, xo + 16), c2 = ld4<false>(a, xo + 32), c3 = ld4<false>(a, xo + 48);
                             lo = mat_cols_xyz(c0, c1, c2, c3, ro, 1.0f);
                             ld = normalize3(mat_cols_xyz(c0, c1, c2, c3, rd, 0.0f));
-                            inv = f3{1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z};
+                            inv = f3{rcp_(ld.x), rcp_(ld.y), rcp_(ld.z)};
                             cull_ok = rtm::abs_(inv.x) < INF && rtm::abs_(inv.y) < INF && rtm::abs_(inv.z) < INF &&
                                       rtm::abs_(lo.x) < INF && rtm::abs_(lo.y) < INF && rtm::abs_(lo.z) < INF;
                         }
@@ -2903,7 +2946,7 @@ hipError_t launch_blend_frames(const BlendArgs& b, hipStream_t stream) {
 // fn: 0 log, 1 cos, 2 sin, 3 exp, 4 exp2, 5 log2, 6 pow(x, y), 7 acos, 8 atan2(x, y), 9 sqrt, 10 x / y
 // (the oracle's numbering), 11 rand() of RNG state bits x -> float, 12 the generator's u32 output for
 // state x, 13 trig_signbits(x), 14 rand_normal_dist() of state x, 15 f32(u32 x) * 2^-32 (rand()'s
-// conversion for a raw generator output), 16 normalize(x, y, x*y).x (division by a sqrt)
+// conversion for a raw generator output), 16 normalize(x, y, x*y).x (division by a sqrt), 17 rcp_(x), 18 sqrt_dev(x)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) rt_units_kernel(int fn, const float* __restrict__ x, const float* __restrict__ y,
                                                        float* __restrict__ out, unsigned long long n) {
@@ -2929,6 +2972,8 @@ __global__ void __launch_bounds__(256) rt_units_kernel(int fn, const float* __re
         case 14: { uint32_t s = __float_as_uint(a); r = rand_normal_dist(s); break; }
         case 15: r = (float)__float_as_uint(a) * 0x1p-32f; break;
         case 16: r = normalize3(f3{a, b, a * b}).x; break;
+        case 17: r = rcp_(a); break;
+        case 18: r = sqrt_dev(a); break;
         default: break;
     }
     out[i] = r;
@@ -2944,6 +2989,30 @@ __global__ void __launch_bounds__(256) rt_units_texture_kernel(const uint8_t* rg
     float o[4];
     rtm::sample_bilinear_words((GWords)(const void*)rgba8, width, height, (GFloats)(const void*)srgb_lut, uv[2 * i], uv[2 * i + 1], o);
     out[4 * i] = o[0]; out[4 * i + 1] = o[1]; out[4 * i + 2] = o[2]; out[4 * i + 3] = o[3];
+}
+
+// Every float x the short forms serve: rcp_core(x) against the compiler's IEEE 1.0f / x (which = 0), sqrt_core(x)
+// against its sqrt (which = 1), bit for bit.  out[0] = floats checked, out[1] = mismatches, out[2] = a mismatching
+// bit pattern.
+__global__ void __launch_bounds__(256) rt_sweep_kernel(int which, unsigned long long* out) {
+    unsigned long long checked = 0, bad = 0;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * 256u + threadIdx.x; b < (1ull << 32); b += (unsigned long long)gridDim.x * 256u) {
+        const float x = __uint_as_float((uint32_t)b);
+        if (which == 0 ? !rcp_in_range(x) : !sqrt_in_range(x)) continue;
+        float q = which == 0 ? 1.0f / x : rtm::sqrt_(x);
+        asm volatile("" : "+v"(q));
+        checked += 1;
+        if (__float_as_uint(which == 0 ? rcp_core(x) : sqrt_core(x)) != __float_as_uint(q)) {
+            bad += 1;
+            out[2] = b;
+        }
+    }
+    atomicAdd(&out[0], checked);
+    if (bad) atomicAdd(&out[1], bad);
+}
+hipError_t launch_sweep(int which, unsigned long long* out, hipStream_t stream) {
+    hipLaunchKernelGGL(rt_sweep_kernel, dim3(4096), dim3(256), 0, stream, which, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_units(int fn, const float* x, const float* y, float* out, unsigned long long n, hipStream_t stream) {

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("RT2_LIB") or os.path.join(_HERE, "librt2_mi355x.so")
 # every symbol include/rt_abi.h declares
 EXPORTS = [
     "rt_create", "rt_upload_scene", "rt_upload_textures", "rt_set_camera", "rt_render",
-    "rt_render_strips", "rt_render_multi", "rt_render_frames", "rt_render_strips_frames", "rt_render_multi_frames", "rt_read_multi_frame", "rt_test_device_units", "rt_test_device_sample_texture", "rt_test_read_wavefront", "rt_strip_texels", "rt_assemble_strips", "rt_read_image", "rt_write_image",
+    "rt_render_strips", "rt_render_multi", "rt_render_frames", "rt_render_strips_frames", "rt_render_multi_frames", "rt_read_multi_frame", "rt_test_device_units", "rt_test_sweep", "rt_test_device_sample_texture", "rt_test_read_wavefront", "rt_strip_texels", "rt_assemble_strips", "rt_read_image", "rt_write_image",
     "rt_synchronize", "rt_get_stats", "rt_last_launch", "rt_reset_timing", "rt_bind_image", "rt_set_stream", "rt_set_option", "rt_set_counters", "rt_device_image", "rt_stream",
     "rt_last_error", "rt_destroy", "rt_version", "rt_device_count", "rt_abi_sizes",
     "rt_scene_load_builtin", "rt_scene_create", "rt_scene_set_camera", "rt_transform_cam",
@@ -61,6 +61,7 @@ def load():
         "rt_render_multi_frames": (i32, [P(vp), i32, P(A.Params), u32, vp]),
         "rt_read_multi_frame": (i32, [vp, vp, C.c_size_t]),
         "rt_test_device_units": (i32, [vp, i32, vp, vp, vp, u64]),
+        "rt_test_sweep": (i32, [vp, i32, vp]),
         "rt_test_device_sample_texture": (i32, [vp, P(A.TextureDesc), vp, vp, u64]),
         "rt_strip_texels": (u64, [u32, u32, u32, u32]),
         "rt_assemble_strips": (i32, [vp, vp, u32, u32, u32]),
@@ -74,7 +75,7 @@ def load():
         "rt_set_option": (i32, [vp, C.c_char_p, i32]),
         "rt_reset_timing": (i32, [vp]),
         "rt_bind_image": (i32, [vp, vp, u64]),
-        "rt_set_stream": (i32, [vp, vp]),
+        "rt_set_stream": (i32, [vp, i32, vp]),
         "rt_device_image": (vp, [vp]),
         "rt_stream": (vp, [vp]),
         "rt_last_error": (C.c_char_p, [vp]),
@@ -108,7 +109,7 @@ def load():
         "rt_scene_num_mesh_instances": (u32, [vp]),
         "rt_scene_last_error": (C.c_char_p, [vp]),
         "rt_scene_destroy": (None, [vp]),
-        "rt_upload_built_scene": (i32, [vp, vp]),
+        "rt_upload_built_scene": (i32, [vp, i32, vp]),
         "rt_scene_subdivide_meshes": (i32, [vp, u32]),
         "rt_export_rgba8": (i32, [vp, u32, u32, vp]),
     }

@@ -122,6 +122,13 @@ class RayTracer:
         self._check(self._L.rt_bind_image(self._h, device_ptr, texels))
 
     # ---- test-only: the device's arithmetic building blocks (tests/test_gpu_device_units.py) ----
+    def sweep(self, which):
+        """(floats checked, mismatches, a mismatching bit pattern) of the kernels' short reciprocal (which = 0) / square root
+        (1) against the compiler's IEEE 1.0f / x / sqrt on the device, over every float the short form serves."""
+        out = (C.c_uint64 * 3)()
+        self._check(self._L.rt_test_sweep(self._h, which, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def device_units(self, fn, x, y=None):
         x = np.ascontiguousarray(x).view(np.float32).ravel()
         y = np.zeros_like(x) if y is None else np.ascontiguousarray(y).view(np.float32).ravel()

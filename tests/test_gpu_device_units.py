@@ -15,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 FN = {"log": 0, "cos": 1, "sin": 2, "exp": 3, "exp2": 4, "log2": 5, "pow": 6, "acos": 7, "atan2": 8, "sqrt": 9,
-      "div": 10, "rand": 11, "rng": 12, "trig_signbits": 13, "rand_normal_dist": 14, "rand_convert": 15, "normalize_x": 16}
+      "div": 10, "rand": 11, "rng": 12, "trig_signbits": 13, "rand_normal_dist": 14, "rand_convert": 15, "normalize_x": 16, "rcp": 17, "sqrt_dev": 18}
 N = 10_000_000
 SPECIAL_BITS = np.array([0x00000000, 0x80000000, 0x00000001, 0x80000001, 0x007fffff, 0x807fffff, 0x00800000, 0x80800000,
                          0x3f800000, 0xbf800000, 0x3f7fffff, 0x3f800001, 0x7f7fffff, 0xff7fffff, 0x7f800000, 0xff800000,
@@ -163,6 +163,40 @@ def test_division_sqrt_normalize_are_correctly_rounded_on_both_sides(tracer, ora
     u = rng.uniform(-3, 3, N // 4).astype(np.float32)
     v = rng.uniform(-3, 3, N // 4).astype(np.float32)
     same_bits(tracer.device_units(FN["normalize_x"], u, v), oracle.transc("normalize_x", u, v))
+
+
+def test_rcp_is_the_ieee_division_for_every_float(tracer, oracle, rng):
+    """The kernels' reciprocal (v_rcp_f32 + one Newton step in fma arithmetic where x and 1/x are normal and away from
+    the denormals, the compiler's IEEE division for the rest of the wave otherwise) is 1.0f / x: the short form is
+    compared with the IEEE division ON THE DEVICE for every float it serves, and the whole function with the CPU's
+    division on samples across the range, the edge of the range, the specials and waves that mix both paths."""
+    checked, bad, first = tracer.sweep(0)
+    # 2 signs x (240 binades [2^-120, 2^120) x 2^23 mantissas + the value 2^120)
+    assert checked == 2 * (240 * 2 ** 23 + 1) and bad == 0, (checked, bad, hex(first))
+    x = with_specials(np.exp(rng.uniform(-88, 88, N)).astype(np.float32) * rng.choice([-1, 1], N).astype(np.float32))
+    one = np.ones_like(x)
+    same_bits(tracer.device_units(FN["rcp"], x), oracle.transc("div", one, x))
+    edge = np.float32(2.0) ** np.float32([-121, -120, -119, 119, 120, 121, -126, -127, 126, 127])
+    edge = np.concatenate([np.nextafter(edge, np.float32(0)), edge, np.nextafter(edge, np.float32(np.inf))])
+    edge = np.concatenate([edge, -edge])
+    mixed = np.where(rng.randint(0, 64, N // 10) == 0, rng.choice(np.concatenate([edge, SPECIAL_BITS.view(np.float32)]), N // 10),
+                     rng.uniform(-4, 4, N // 10).astype(np.float32)).astype(np.float32)
+    for v in (edge, mixed):
+        same_bits(tracer.device_units(FN["rcp"], v), oracle.transc("div", np.ones_like(v), v))
+
+
+def test_sqrt_dev_is_the_ieee_square_root_for_every_float(tracer, oracle, rng):
+    """The same for the kernels' square root (v_sqrt_f32 + the neighbour test, without the scaling for denormals)."""
+    checked, bad, first = tracer.sweep(1)
+    assert checked == 200 * 2 ** 23 + 1 and bad == 0, (checked, bad, hex(first))   # [2^-100, 2^100]
+    x = with_specials(np.exp(rng.uniform(-88, 88, N)).astype(np.float32))
+    same_bits(tracer.device_units(FN["sqrt_dev"], x), oracle.transc("sqrt", x))
+    edge = np.float32(2.0) ** np.float32([-101, -100, -99, 99, 100, 101, -126, -127, 126, 127])
+    edge = np.concatenate([np.nextafter(edge, np.float32(0)), edge, np.nextafter(edge, np.float32(np.inf)), -edge])
+    mixed = np.where(rng.randint(0, 64, N // 10) == 0, rng.choice(np.concatenate([edge, SPECIAL_BITS.view(np.float32)]), N // 10),
+                     rng.uniform(0, 4, N // 10).astype(np.float32)).astype(np.float32)
+    for v in (edge, mixed):
+        same_bits(tracer.device_units(FN["sqrt_dev"], v), oracle.transc("sqrt", v))
 
 
 def test_texture_filter(tracer, oracle, rng):
