@@ -376,7 +376,7 @@ def main():
             "value_definition": f"value = rays of {args.steps} frames / wall time with {frames_per_launch:g} frames per launch "
                                 "(intermediate frames of a batch are not observable); value_per_frame_launch = the same frames "
                                 "with one launch" + (" and one gather" if world > 1 else "") + " per frame, every frame observable, timed "
-                                "right after (N = 1: consecutive launches pipelined across internal streams, three frames in flight, option pipeline; "
+                                "right after (N = 1: consecutive launches pipelined across internal streams, four frames in flight, option pipeline; "
                                 "ms_per_frame_unoverlapped = the same with the pipeline off = a frame's latency)",
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "CornellBox-Original.obj/.mtl of the reference through the loader + BVH builder "

@@ -90,19 +90,20 @@ struct rt_handle {
     // Pipelined single frames (option "pipeline"): consecutive rt_render calls sample into two or three scratch images, each
     // on an internal stream of its own, and are blended in frame order on the handle's stream, so frame k + 1's launch takes the CUs that
     // frame k's draining waves free -- every frame stays observable (rt_read_image after any call returns that frame).
-    int pipeline = 3;                                  // option "pipeline": frames in flight (0 = off, 2, 3; config 2: 1.59 / 1.34 / 1.30 ms per frame)
-    hipStream_t pipe_stream[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t pipe_sampled[3] = {nullptr, nullptr, nullptr};   // frame sampled into scratch[i] (recorded on pipe_stream[i])
-    hipEvent_t pipe_blended[3] = {nullptr, nullptr, nullptr};   // ... and blended out of it (recorded on the handle's stream)
+    int pipeline = 4;                                  // option "pipeline": frames in flight (0 = off, 2 .. 4; config 2: 1.51 / 1.27 / 1.23 / 1.20 ms per frame; 5 and 6: 1.25, 1.24)
+    static constexpr int PIPE_MAX = 4;                 // most frames in flight (option "pipeline")
+    hipStream_t pipe_stream[PIPE_MAX] = {};
+    hipEvent_t pipe_sampled[PIPE_MAX] = {};            // frame sampled into scratch[i] (recorded on pipe_stream[i])
+    hipEvent_t pipe_blended[PIPE_MAX] = {};            // ... and blended out of it (recorded on the handle's stream)
     hipEvent_t pipe_book = nullptr;                    // the last tile-order / primary-table rebuild (recorded on a pipe stream)
     hipEvent_t pipe_main = nullptr;                    // the last launch that was not pipelined (recorded on the handle's stream)
-    bool pipe_sampled_set[3] = {false, false, false}, pipe_blended_set[3] = {false, false, false}, pipe_book_set = false, pipe_main_set = false;
-    float4* pipe_scratch[3] = {nullptr, nullptr, nullptr};
+    bool pipe_sampled_set[PIPE_MAX] = {}, pipe_blended_set[PIPE_MAX] = {}, pipe_book_set = false, pipe_main_set = false;
+    float4* pipe_scratch[PIPE_MAX] = {};
     size_t pipe_scratch_texels = 0;
-    uint32_t* pipe_work[3] = {nullptr, nullptr, nullptr};       // a ring of launch counters per pipe stream
-    uint32_t pipe_work_slot[3] = {0, 0, 0};
-    uint32_t* pipe_memo[3] = {nullptr, nullptr, nullptr};       // further global-memory primary-ray memos (pixel_cache == 2)
-    size_t pipe_memo_words[3] = {0, 0, 0};
+    uint32_t* pipe_work[PIPE_MAX] = {};                // a ring of launch counters per pipe stream
+    uint32_t pipe_work_slot[PIPE_MAX] = {};
+    uint32_t* pipe_memo[PIPE_MAX] = {};                // further global-memory primary-ray memos (pixel_cache == 2)
+    size_t pipe_memo_words[PIPE_MAX] = {};
     uint32_t pipe_seq = 0;
     float4* small_blob = nullptr;
     SceneLayout small_lay{};
@@ -434,7 +435,7 @@ void rt_destroy(rt_handle* h) {
     free_dev(h->park_queue[0]);
     free_dev(h->park_queue[1]);
     free_dev(h->park_counts);
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < rt_handle::PIPE_MAX; ++k) {
         free_dev(h->pipe_memo[k]);
         if (h->pipe_stream[k]) {
             (void)hipStreamSynchronize(h->pipe_stream[k]);
@@ -1116,8 +1117,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         if (value < 0 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "wavefront must be 0 (off) or 1 (whenever legal)");
         h->wavefront = value;
     } else if (n == "pipeline") {
-        if (value < 0 || value > 3) return fail(h, RT_ERR_INVALID_ARGUMENT, "pipeline must be 0 (off), 2 or 3 (frames in flight)");
-        h->pipeline = value == 1 ? 3 : value;
+        if (value < 0 || value > rt_handle::PIPE_MAX) return fail(h, RT_ERR_INVALID_ARGUMENT, "pipeline must be 0 (off) or 2 .. 4 (frames in flight)");
+        h->pipeline = value == 1 ? 4 : value;
     } else if (n == "fast_miss") {
         h->fast_miss = value ? 1 : 0;
     } else if (n == "park_levels") {
@@ -1337,15 +1338,15 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     const bool wavefront_wanted = h->wavefront != 0 && a.many_mesh != 0 && !h->any_deep && params->debug_flag == 0 && params->rays_per_pixel > 0;
     // Pipelined single frames: a plain one-frame launch (no batch, no sequence of launches).
     // S is the stream this frame's sampling launch and its bookkeeping run on.
-    const uint32_t pipe_depth = h->pipeline >= 3 ? 3u : 2u;
+    const uint32_t pipe_depth = h->pipeline >= 2 ? (uint32_t)h->pipeline : 2u;
     const bool pipe = h->pipeline != 0 && n_batch == 0 && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
                       !rounds && !wavefront_wanted;   // (strips too: the gather reads the image behind the blend, on the handle's stream)
     const uint32_t pslot = h->pipe_seq % pipe_depth;
     hipStream_t S = h->stream;
     bool pipe_barrier = false;  // this frame rewrites shared tables (tile order, primary rays): the other stream's frame has to be done
     if (pipe) {
-        h->pipe_seq = (h->pipe_seq + 1) % 6u;
-        for (int k = 0; k < 3; ++k) {
+        h->pipe_seq = (h->pipe_seq + 1) % 12u;   // (a multiple of every depth)
+        for (int k = 0; k < (int)pipe_depth; ++k) {   // (no more streams than frames in flight: they share the process's hardware queues)
             if (!h->pipe_stream[k]) HIP_TRY(h, hipStreamCreateWithFlags(&h->pipe_stream[k], hipStreamNonBlocking));
             if (!h->pipe_sampled[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_sampled[k], hipEventDisableTiming));
             if (!h->pipe_blended[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_blended[k], hipEventDisableTiming));
@@ -1359,13 +1360,14 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         if (!h->pipe_main) HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_main, hipEventDisableTiming));
         if (h->pipe_scratch_texels < need_texels) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));   // (the blends on this stream wait for every sampling launch)
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < rt_handle::PIPE_MAX; ++k) {
                 free_dev(h->pipe_scratch[k]);
-                HIP_TRY(h, hipMalloc((void**)&h->pipe_scratch[k], need_texels * sizeof(float4)));
+                h->pipe_scratch[k] = nullptr;
                 h->pipe_blended_set[k] = false;
             }
             h->pipe_scratch_texels = need_texels;
         }
+        if (!h->pipe_scratch[pslot]) HIP_TRY(h, hipMalloc((void**)&h->pipe_scratch[pslot], h->pipe_scratch_texels * sizeof(float4)));
         S = h->pipe_stream[pslot];
         // this frame's scratch image is free once the frame before last has been blended out of it; the tables the last
         // bookkeeping frame rewrote are complete; whatever the handle's stream did outside the pipeline is complete
@@ -1386,7 +1388,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     auto barrier_other = [&]() -> hipError_t {   // before rewriting a shared table: the other stream's sampling launch is done
         if (!pipe || pipe_barrier) return hipSuccess;
         pipe_barrier = true;
-        for (uint32_t k = 0; k < 3u; ++k)
+        for (uint32_t k = 0; k < (uint32_t)rt_handle::PIPE_MAX; ++k)
             if (k != pslot && h->pipe_sampled_set[k]) {
                 const hipError_t e = hipStreamWaitEvent(S, h->pipe_sampled[k], 0);
                 if (e != hipSuccess) return e;

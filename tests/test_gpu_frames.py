@@ -335,7 +335,7 @@ def test_independent_frames_pipelined_across_two_handles(rt, oracle, cornell):
 
 
 def test_pipelined_single_frames(rt, oracle, tracer, cornell):
-    """Option pipeline (default: three frames in flight): consecutive rt_render calls sample into scratch images on internal
+    """Option pipeline (default: four frames in flight): consecutive rt_render calls sample into scratch images on internal
     streams and are blended in frame order on the handle's stream.  Forty frames without a synchronisation in between -- across tile-order
     refreshes (every 8 frames), a camera change (primary-ray table rebuilt), a change of frame size, a batch in the middle,
     an image written by the host -- equal the same calls with the pipeline off, and the first frames equal the oracle's;
@@ -368,7 +368,7 @@ def test_pipelined_single_frames(rt, oracle, tracer, cornell):
     try:
         tracer.set_option("pipeline", 0)
         want = script(tracer)
-        for depth in (2, 3):   # frames in flight
+        for depth in (2, 3, 4):   # frames in flight
             tracer.set_option("pipeline", depth)
             got = script(tracer)
             assert len(got) == len(want)
@@ -391,7 +391,7 @@ def test_pipelined_single_frames_global_memory_scene(rt, tracer):
         tracer.load_scene(arrays)
         outs = []
         try:
-            for pipe in (0, 3):
+            for pipe in (0, 3, 4):
                 tracer.set_option("pipeline", pipe)
                 tracer.write_image(np.zeros((h, w, 4), np.float32))
                 tracer.reset_timing()
@@ -400,4 +400,5 @@ def test_pipelined_single_frames_global_memory_scene(rt, tracer):
                 outs.append((tracer.read_image(w, h).copy(), tracer.stats().segments))
         finally:
             tracer.set_option("pipeline", 1)
-        assert np.array_equal(bits(outs[0][0]), bits(outs[1][0])) and outs[0][1] == outs[1][1]
+        for o in outs[1:]:
+            assert np.array_equal(bits(outs[0][0]), bits(o[0])) and outs[0][1] == o[1]
