@@ -19,8 +19,8 @@ tr = rt.RayTracer(0, W, H)
 tr.load_scene(arrays)
 base = {}
 # (mode, frames per launch, option pipeline): wall time per frame -- pipelined launches overlap, their event times do not add up
-for mode, batch, pipe in (("one launch per frame, no pipeline", 1, 0), ("one launch per frame, pipelined (default)", 1, 3),
-                          ("32 frames per launch", 32, 3)):
+for mode, batch, pipe in (("one launch per frame, no pipeline", 1, 0), ("one launch per frame, pipelined (default)", 1, 4),
+                          ("32 frames per launch", 32, 4)):
     tr.set_option("batch_frames", batch)
     tr.set_option("pipeline", pipe)
     for world in (1, 2, 4, 8):
