@@ -3,6 +3,11 @@
 The product is the C-ABI library `librt2_mi355x.so` (include/rt_abi.h):
 hand-written HIP for gfx950 plus the C++ host-side scene pipeline.  This
 package is the thin Python face used by tests and bench.py.
+
+In a process that also uses PyTorch on the GPU, import torch FIRST (bench.py does): the torch wheel brings its own
+HIP runtime (ROCm 7.0), the library is linked against the image's (ROCm 7.2), and whichever is loaded first serves
+both -- torch on the image's runtime reports "no ROCm-capable device" (tests/_bench_plumbing.py runs in a process
+of its own for that reason).
 """
 import os as _os
 

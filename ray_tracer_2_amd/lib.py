@@ -75,7 +75,7 @@ def load():
         "rt_set_option": (i32, [vp, C.c_char_p, i32]),
         "rt_reset_timing": (i32, [vp]),
         "rt_bind_image": (i32, [vp, vp, u64]),
-        "rt_set_stream": (i32, [vp, i32, vp]),
+        "rt_set_stream": (i32, [vp, vp]),
         "rt_device_image": (vp, [vp]),
         "rt_stream": (vp, [vp]),
         "rt_last_error": (C.c_char_p, [vp]),
@@ -109,7 +109,7 @@ def load():
         "rt_scene_num_mesh_instances": (u32, [vp]),
         "rt_scene_last_error": (C.c_char_p, [vp]),
         "rt_scene_destroy": (None, [vp]),
-        "rt_upload_built_scene": (i32, [vp, i32, vp]),
+        "rt_upload_built_scene": (i32, [vp, vp]),
         "rt_scene_subdivide_meshes": (i32, [vp, u32]),
         "rt_export_rgba8": (i32, [vp, u32, u32, vp]),
     }

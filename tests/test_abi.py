@@ -23,6 +23,22 @@ def test_every_declared_symbol_is_exported(rt):
     assert sorted(EXPORTS) == declared
 
 
+def test_prototypes_take_as_many_arguments_as_the_header_declares(rt):
+    """ctypes checks the argument COUNT of a call against argtypes: a prototype in lib.py with one argument too many makes
+    every call of that function a TypeError (rt_set_stream once: only bench.py --gpus N called it)."""
+    text = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    L = rt.load()
+    seen = 0
+    for name, args in re.findall(r"\b(rt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = args.strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        fn = getattr(L, name)
+        assert fn.argtypes is not None and len(fn.argtypes) == n, (name, n, fn.argtypes)
+        seen += 1
+    assert seen >= 40
+
+
 def test_struct_sizes_match_reference_layout(rt):
     # SURVEY.md 8a T1-T8 (bytes): Params 48, Material 96, Sphere 112, MeshUniform 240,
     # Node 48, PackedTriangle 96, CameraUniform 84, SceneUniform 128

@@ -1,6 +1,8 @@
 """Frame batches (rt_render_frames) and the multi-GPU entry points: the accumulated image after n
 overlapped frames must be bit-identical to n sequential rt_render calls with Params.frames advancing
 (app.rs:44-53 + wgsl:154-161), on one GPU, per strip, and through rt_render_multi."""
+import os
+
 import numpy as np
 import pytest
 
@@ -169,6 +171,20 @@ def test_strip_frames_assemble_to_the_full_frames(rt, tracer, cornell, sponza, s
     assert np.array_equal(bits(tracer.read_image(w, h)), bits(full))
     small.close()
     stage.close()
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_bench_rank_plumbing_on_torch_memory_and_stream(batch):
+    """What `bench.py --gpus N` does per rank, all ranks in one process: every rank renders its strips straight into a
+    torch tensor (rt_bind_image) on torch's current side stream (rt_set_stream), the tensors are stacked as the gather
+    would deliver them, the root assembles into a torch frame (rt_assemble_strips) -- with batches and with one
+    (pipelined) launch per frame, no host synchronisation inside a step; == rt_render over the same frames.
+    (A process of its own, torch imported first as in bench.py: torch brings its own HIP runtime.)"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bench_plumbing.py"), str(batch)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "plumbing ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("scene_name", ["cornell", "sponza"])
