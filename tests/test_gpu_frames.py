@@ -173,7 +173,7 @@ def test_strip_frames_assemble_to_the_full_frames(rt, tracer, cornell, sponza, s
     stage.close()
 
 
-@pytest.mark.parametrize("batch", [1, 4])
+@pytest.mark.parametrize("batch", [1, 4, "rccl"])
 def test_bench_rank_plumbing_on_torch_memory_and_stream(batch):
     """What `bench.py --gpus N` does per rank, all ranks in one process: every rank renders its strips straight into a
     torch tensor (rt_bind_image) on torch's current side stream (rt_set_stream), the tensors are stacked as the gather
@@ -182,7 +182,8 @@ def test_bench_rank_plumbing_on_torch_memory_and_stream(batch):
     (A process of its own, torch imported first as in bench.py: torch brings its own HIP runtime.)"""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bench_plumbing.py"), str(batch)],
+    args = ["4", "rccl"] if batch == "rccl" else [str(batch)]   # "rccl": the gather through torch.distributed's nccl backend (one rank)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bench_plumbing.py"), *args],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "plumbing ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
