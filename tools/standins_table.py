@@ -75,7 +75,7 @@ def main():
         ("config 5 geometry: dragon.obj x121 (1,054,152 triangles), 1920x1080, 8 spp, 4 bounces", lambda: dragon(11),
          1920, 1080, 8, 4, [(1, 8), (16, 32)]),
         ("config 5 stand-in at its BASELINE size: dragon.obj x121, 3840x2160, 64 spp, 8 bounces", None,
-         3840, 2160, 64, 8, [(1, 2), (4, 4)]),
+         3840, 2160, 64, 8, [(1, 2), (4, 4), (8, 8)]),
     ]
     last = None
     for name, make, w, h, spp, nb, runs in cases:
