@@ -1160,6 +1160,23 @@ uint64_t rt_strip_texels(uint32_t width, uint32_t height, uint32_t rank, uint32_
 // One launch of the hot path: a single frame (n_batch == 0: wgsl `main`, blending in place), or a batch
 // of n_batch >= 2 consecutive frames (Params.frames advancing by one each, app.rs:44-53) sampled in one
 // persistent launch over (frame, tile) work items and blended in frame order by a dense second kernel.
+// Sum of the recorded launch times (HIP events around every launch since rt_reset_timing).  The pairs are recorded on
+// whichever stream the launch ran on -- the pipelined frames' internal streams too -- and synchronising the handle's
+// stream only proves that the KERNELS before a pair's second event are done (the blends wait for them), not that the
+// runtime has retired the event itself: every pair is synchronised before it is read (hipEventElapsedTime on an event
+// that is not ready is hipErrorNotReady; seen once in 850 fuzz scenes with four frames in flight).
+static hipError_t harvest_event_times(rt_handle* h, double& sum_ms) {
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        hipError_t e = hipEventSynchronize(h->ev_pool[i].second);
+        if (e != hipSuccess) return e;
+        float ms = 0.0f;
+        e = hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second);
+        if (e != hipSuccess) return e;
+        sum_ms += ms;
+    }
+    return hipSuccess;
+}
+
 static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world, uint32_t n_batch = 0) {
     if (!h || !params) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
     if (!h->have_scene) return fail(h, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
@@ -1551,12 +1568,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     if (h->ev_used == h->ev_pool.size()) {
         if (h->ev_pool.size() >= 4096) {
             // the pool is full: add the recorded times to the running total, then reuse the events
-            HIP_TRY(h, hipEventSynchronize(h->ev_pool[h->ev_used - 1].second));
-            for (size_t i = 0; i < h->ev_used; ++i) {
-                float ms = 0.0f;
-                HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
-                h->ev_ms_harvested += ms;
-            }
+            HIP_TRY(h, harvest_event_times(h, h->ev_ms_harvested));
             h->ev_used = 0;
         } else {
             hipEvent_t s0 = nullptr, s1 = nullptr;
@@ -2033,11 +2045,7 @@ int rt_get_stats(rt_handle* h, rt_stats* out) {
     out->segments_reused = c.reused;
     // counters accumulate over all launches since rt_reset_timing
     double total = h->ev_ms_harvested;
-    for (size_t i = 0; i < h->ev_used; ++i) {
-        float ms = 0.0f;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
-        total += ms;
-    }
+    HIP_TRY(h, harvest_event_times(h, total));
     out->kernel_ms = (float)total;
     out->launches = (uint32_t)h->launches_total;
     out->frames = (uint32_t)h->frames_total;
@@ -2067,11 +2075,7 @@ int rt_set_stream(rt_handle* h, void* hip_stream) {
     HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = wait_pending_copy(h); rc != RT_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (size_t i = 0; i < h->ev_used; ++i) {  // (the old stream is idle: its recorded times are final)
-        float ms = 0.0f;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
-        h->ev_ms_harvested += ms;
-    }
+    HIP_TRY(h, harvest_event_times(h, h->ev_ms_harvested));  // (the old stream is idle: its recorded times are final)
     h->ev_used = 0;
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return RT_OK;
