@@ -62,6 +62,11 @@ class RayTracer:
             a.meshes.shape[0], a.triangles.ctypes.data, a.triangles.shape[0], a.nodes.ctypes.data,
             a.nodes.shape[0]))
 
+    def load_built_scene(self, scene):
+        """A built Scene (C++ object) straight to the device: textures + arrays, without the round trip through numpy
+        (rt_upload_built_scene: what the C++ mirror's load_scene_gpu_resources + update_buffers do)."""
+        self._check(self._L.rt_upload_built_scene(self._h, scene._p))
+
     def load_scene(self, scene):
         """Scene (C++ object) or SceneArrays -> device."""
         arrays = SceneArrays.from_scene(scene) if isinstance(scene, Scene) else scene

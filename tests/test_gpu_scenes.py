@@ -865,3 +865,22 @@ def test_wavefront_sequences_do_not_change_the_bits(rt, oracle, tracer):
         tracer.set_counters(False)
         tracer.set_option("wavefront", 0)
         tracer.set_option("pixel_cache", 1)
+
+
+def test_upload_built_scene_equals_the_array_upload(rt, tracer):
+    """rt_upload_built_scene (a built C++ scene straight to the device) == rt_upload_textures + rt_upload_scene of its arrays."""
+    from ray_tracer_2_amd import scenes
+    sc = scenes.sponza_standin(24)
+    w, h = 160, 96
+    p = rt.make_params(w, h, 3, 2, skybox=1, frames=0)
+    tracer.load_scene(rt.SceneArrays.from_scene(sc))
+    tracer.render(p)
+    want = tracer.read_image(w, h).copy()
+    other = rt.RayTracer(0, w, h)
+    try:
+        other.load_built_scene(sc)
+        other.render(p)
+        assert np.array_equal(other.read_image(w, h).view(np.uint32), want.view(np.uint32))
+    finally:
+        other.close()
+
