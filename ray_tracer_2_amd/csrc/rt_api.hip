@@ -1346,7 +1346,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     // LDS and walked by the few-mesh kernels (config 2: 1.221 ms per frame; 1.222 with 7/8 and 16, 1.366 with 8/8), 7/8 or
     // 16 iterations otherwise (sponza-sized stand-in 10.69 -> 10.21 ms, 200-mesh stand-in 5.00 -> 4.85), every lane or 16
     // iterations in a deferred-walk sequence, whose resumed pixels arrive in every phase (config 3 stand-in 5.86 -> 5.45,
-    // config 5 geometry 3.35 -> 3.22; gpurun_out/r3w/ab_*_vote*.txt).
+    // config 5 geometry 3.35 -> 3.22; profiles/r03_experiments/ab_*_vote*.txt).
     {
         const bool costly = a.lds_scene == 0u || a.many_mesh != 0u;
         a.vote_eighths = h->vote_eighths >= 0 ? (uint32_t)h->vote_eighths : rounds ? 8u : costly ? 7u : 6u;
