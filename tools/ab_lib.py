@@ -32,7 +32,7 @@ def child(a):
                                                                  subdivide=n, device=0 if n > 3 else None))
     else:
         n = int(a.scene[6:])
-        arrays = rt.SceneArrays.from_scene(scenes.sponza_standin(n, detail=8 if n >= 300 else 1))
+        arrays = rt.SceneArrays.from_scene(scenes.sponza_standin(n, detail=a.detail if a.detail else (8 if n >= 300 else 1)))
     tr = rt.RayTracer(0, a.w, a.h)
     for kv in (a.opts or "").split(","):
         if kv:
@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--w", type=int, default=1920)
     ap.add_argument("--h", type=int, default=1080)
     ap.add_argument("--opts", default="")
+    ap.add_argument("--detail", type=int, default=0, help="sponza stand-in: triangles per mesh = 12 x detail^2 (default 8 from 300 meshes, else 1)")
     ap.add_argument("--child", action="store_true")
     a = ap.parse_args()
     if a.child:
@@ -89,7 +90,7 @@ def main():
             env = dict(os.environ, RT2_LIB=os.path.abspath(path))
             opts = ",".join(x for x in (a.opts, own) if x)
             cmd = [sys.executable, os.path.abspath(__file__), "--child", "--scene", a.scene, "--spp", str(a.spp), "--bounces", str(a.bounces),
-                   "--batch", str(a.batch), "--frames", str(a.frames), "--w", str(a.w), "--h", str(a.h), "--opts", opts]
+                   "--batch", str(a.batch), "--frames", str(a.frames), "--w", str(a.w), "--h", str(a.h), "--detail", str(a.detail), "--opts", opts]
             out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             if out.returncode != 0:
                 print(l, "FAILED:", out.stderr[-400:], flush=True)
