@@ -388,14 +388,16 @@ def test_random_many_mesh_scenes(rt, oracle, tracer, seed):
 @pytest.mark.parametrize("knobs", [{"forest": 0}, {"stack_wide": 1}, {"stack_wide": 0}, {"pixel_cache": 0}, {"pixel_cache": 2}, {"primary_table": 0},
                                    {"forest": 0, "stack_wide": 1, "pixel_cache": 2},
                                    {"lds_top": -1}, {"lds_top": 1}, {"lds_top": 77}, {"lds_top": 2048}, {"flat2": 0}, {"flat2": 0, "forest": 0},
-                                   {"specialise": 0}, {"specialise": 0, "kernel_variant": 1}, {"specialise": 1, "kernel_variant": 1}],
+                                   {"specialise": 0}, {"specialise": 0, "kernel_variant": 1}, {"specialise": 1, "kernel_variant": 1},
+                                   {"fast_miss": 0}, {"fast_miss": 0, "kernel_variant": 1}, {"vote_eighths": 8, "vote_patience": 16},
+                                   {"vote_eighths": 0}, {"vote_eighths": 7, "vote_patience": 0}],
                          ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
 def test_tuning_knobs_do_not_change_the_bits(rt, oracle, tracer, cornell, dragon_arrays, knobs):
     """rt_set_option's contract: results never depend on the knobs (forest items, stack entry
     width, memo placement, the LDS-staged BVH top) -- on the LDS-resident Cornell scene and the
     global-memory dragon scene."""
     defaults = {"forest": 1, "stack_wide": -1, "pixel_cache": 1, "primary_table": 1, "lds_top": 0, "flat2": 1, "specialise": 1,
-                "kernel_variant": -1}
+                "kernel_variant": -1, "fast_miss": 1, "vote_eighths": -1, "vote_patience": -1}
     try:
         for name, value in knobs.items():
             tracer.set_option(name, value)
@@ -489,6 +491,28 @@ def test_deferred_walks_do_not_change_the_bits(rt, oracle, tracer, dragon_arrays
             tracer.render(p)
             assert same(tracer.read_image(W, H), ref1), ("hybrid, one frame", rounds)
         tracer.set_option("hybrid", 0)
+        # option park_levels = 0: every ray that can hit the root box parks (round 2's rule) instead of only those that reach
+        # a grandchild box; and the vote's thresholds are free (the defaults inside a sequence are 8/8 and 16)
+        for knobs in ({"park_levels": 0}, {"vote_eighths": 6, "vote_patience": 3}, {"vote_eighths": 0}, {"fast_miss": 0}):
+            for name, value in knobs.items():
+                tracer.set_option(name, value)
+            for counters in (False, True):
+                tracer.set_counters(counters)
+                tracer.set_option("sort_rounds", 3)
+                tracer.write_image(np.zeros((H, W, 4), np.float32))
+                tracer.reset_timing()
+                tracer.render(p)
+                s = tracer.stats()
+                assert same(tracer.read_image(W, H), ref1), (knobs, counters)
+                assert s.segments == st1.segments
+                if counters:
+                    assert (s.node_tests, s.triangle_tests) == (st1.node_tests, st1.triangle_tests), knobs
+            tracer.set_counters(False)
+            tracer.write_image(np.zeros((H, W, 4), np.float32))
+            tracer.render_frames(p, 3)
+            assert same(tracer.read_image(W, H), acc), (knobs, "batch")
+            for name, value in {"park_levels": 1, "vote_eighths": -1, "vote_patience": -1, "fast_miss": 1}.items():
+                tracer.set_option(name, value)
         # the automatic setting (engages from eight 1920 x 1080 x 16 spp frames' worth of paths per launch: here 32
         # frames of 240 x 135 at 256 spp): against the plain kernels
         tracer.set_option("batch_frames", 32)
