@@ -17,12 +17,13 @@ from test_gpu_scenes import _random_scene  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-tr = rt.RayTracer(0, 256, 256)
+tr = rt.RayTracer(0, 256 * int(os.environ.get("FUZZ_SCALE", 1)), 256 * int(os.environ.get("FUZZ_SCALE", 1)))
 bad = 0
 for seed in range(first, first + count):
     arrays = _random_scene(rt, seed, many=seed % 4 == 3)   # every fourth: 5-40 meshes per transform group (top-level trees)
     tr.set_option("tlas_min", 2 if seed % 8 == 7 else 8)
-    w, h = 64 + 8 * (seed % 9), 40 + 4 * (seed % 7)
+    scale = int(os.environ.get("FUZZ_SCALE", 1))   # larger frames: many tiles per resident wave, refill and pipelining at work
+    w, h = scale * (64 + 8 * (seed % 9)) + (seed % 5 if scale > 1 else 0), scale * (40 + 4 * (seed % 7)) + (seed % 3 if scale > 1 else 0)
     p = rt.make_params(w, h, 1 + seed % 6, 1 + seed % 4, skybox=seed % 2, frames=0)
     ref, st = oracle.render(p, arrays)
     tr.load_scene(arrays)
