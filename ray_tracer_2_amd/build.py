@@ -18,7 +18,7 @@ PRODUCT_SOURCES = [
     "host/png_decode.cpp", "host/scene_capi.cpp", "host/ray_tracer.cpp",
 ]
 PRODUCT_HEADERS = [
-    "rt_transc.h", "rt_texture.h", "rt_srgb_lut.h", "rt_device.h", "host/glam_math.h",
+    "rt_transc.h", "rt_texture.h", "rt_srgb_lut.h", "rt_device.h", "rt_rccl.h", "host/glam_math.h",
     "host/obj_loader.h", "host/bvh.h", "host/scene.h", "host/ray_tracer.hpp",
     "../../include/rt_abi.h",
 ]

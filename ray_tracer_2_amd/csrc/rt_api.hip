@@ -7,11 +7,10 @@
 // aborts across the boundary).
 #include <hip/hip_runtime.h>
 
-#include <dlfcn.h>
-#include <rccl/rccl.h>  // types only: the library is loaded on first multi-device use
 
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -21,6 +20,7 @@
 #include <vector>
 
 #include "rt_device.h"
+#include "rt_rccl.h"  // (types of <rccl/rccl.h>; the library itself is loaded on first multi-device use)
 #include "rt_srgb_lut.h"
 
 namespace rtd {
@@ -184,6 +184,7 @@ struct rt_handle {
     bool lds_scene = false;
     bool roots_are_unions = false;  // every internal root's box is the exact union of its children's
     int cull_roots = -1;            // option: -1 auto (many meshes), 0 off, 1 on (if provable)
+    int cross_prune = 1;            // option "cross_prune": cross-mesh pruning in the many-mesh product kernels (RenderArgs::cross_prune)
     int force_global = 0;  // option "lds_scene" = 0 disables LDS staging (tuning / tests)
     DTexture* textures = nullptr;
     std::vector<uint8_t*> texture_data;
@@ -303,54 +304,15 @@ int mesh_bvh_height(const rt_node* nodes, uint32_t n_nodes, uint32_t node_offset
 }  // namespace
 
 namespace {
-struct RcclApi {
-    void* lib = nullptr;
-    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    std::string why;
-    bool load() {
-        if (lib) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (lib) break;
-        }
-        if (!lib) {
-            why = std::string("cannot load librccl: ") + dlerror();
-            return false;
-        }
-        auto sym = [&](const char* n) { void* f = dlsym(lib, n); if (!f) why = std::string("librccl lacks ") + n; return f; };
-        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
-        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
-        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
-        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
-        Send = (decltype(Send))sym("ncclSend");
-        Recv = (decltype(Recv))sym("ncclRecv");
-        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
-            dlclose(lib);
-            lib = nullptr;
-            return false;
-        }
-        return true;
-    }
-};
 RcclApi g_rccl;
 
-#define NCCL_TRY(h, expr)                                                                          \
-    do {                                                                                           \
-        ncclResult_t r_ = (expr);                                                                  \
-        if (r_ != ncclSuccess)                                                                     \
-            return fail(h, RT_ERR_DEVICE, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
-    } while (0)
-
-void multi_drop_comms(rt_handle* root) {
+// (abort: the communicators' last group failed -- ncclCommAbort where the library has it)
+void multi_drop_comms(rt_handle* root, bool abort = false) {
     if (g_rccl.lib)
-        for (void* c : root->multi_comms) (void)g_rccl.CommDestroy((ncclComm_t)c);
+        for (void* c : root->multi_comms) {
+            if (abort) g_rccl.drop((ncclComm_t)c);
+            else (void)g_rccl.CommDestroy((ncclComm_t)c);
+        }
     root->multi_comms.clear();
     root->multi_comm_devices.clear();
 }
@@ -789,6 +751,99 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                     if (it.kind & ITEM_TLAS) it.a = new_of[it.a];
             }
         }
+        // ---- cross-mesh pruning (RenderArgs::cross_prune): which items may be cut, and the order of the loop ----
+        // An item gets ITEM_PRUNE when every mesh of it (a) has the model_to_world of the mesh that gives the item's
+        // local ray, bit for bit -- the kernel's bound on the world distance is derived from that matrix --, (b) is
+        // not glass (no backface culling: a ray leaving a surface is not culled against the coplanar triangles next
+        // to it, the one place where the triangle test's parameter is noise), (c) is walked with
+        // the ordinary stack, and (d) has a BVH that is a proper bounding hierarchy: finite boxes, every child box inside
+        // its parent's, every leaf triangle inside its leaf's box (true of the reference's builder; verified, since
+        // BVHs may be foreign).
+        auto hierarchy_ok = [&](uint32_t i) {
+            const rt_mesh_uniform& m = meshes[i];
+            const rt_node* mn = nodes + m.node_offset;
+            auto finite_box = [](const rt_node& n) {
+                for (int k = 0; k < 3; ++k)
+                    if (!(n.aabb_min[k] <= n.aabb_max[k] && n.aabb_min[k] - n.aabb_min[k] == 0.0f && n.aabb_max[k] - n.aabb_max[k] == 0.0f)) return false;
+                return true;
+            };
+            std::vector<uint32_t> st{0u};
+            while (!st.empty()) {
+                const rt_node& n = mn[st.back()];
+                st.pop_back();
+                if (!finite_box(n)) return false;
+                if (n.count > 0) {
+                    for (uint32_t t = 0; t < n.count; ++t) {
+                        const rt_packed_triangle& p = triangles[m.triangle_offset + n.first + t];
+                        for (const float* v : {p.v1, p.v2, p.v3})
+                            for (int k = 0; k < 3; ++k)
+                                if (!(v[k] >= n.aabb_min[k] && v[k] <= n.aabb_max[k])) return false;
+                    }
+                } else {
+                    for (uint32_t c : {n.left, n.right}) {
+                        const rt_node& ch = mn[c];
+                        for (int k = 0; k < 3; ++k)
+                            if (!(ch.aabb_min[k] >= n.aabb_min[k] && ch.aabb_max[k] <= n.aabb_max[k])) return false;
+                        st.push_back(c);
+                    }
+                }
+            }
+            return true;
+        };
+        std::vector<signed char> prune_ok_memo(n_meshes, -1);
+        auto mesh_prune_ok = [&](uint32_t i, uint32_t xform_mesh) {
+            if (prune_ok_memo[i] < 0)
+                prune_ok_memo[i] = (!deep[i] && meshes[i].material.flag != RT_MATERIAL_GLASS && hierarchy_ok(i)) ? 1 : 0;
+            return prune_ok_memo[i] == 1 && memcmp(meshes[i].model_to_world, meshes[xform_mesh].model_to_world, 64) == 0;
+        };
+        if (any_tlas || n_meshes >= 16) {  // (the scenes the many-mesh kernels render)
+            // members of a tree, per tree item (the trees are not renumbered again below)
+            auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+            for (Item& it : items) {
+                bool ok = true;
+                if (it.kind & ITEM_TLAS) {
+                    std::vector<uint32_t> st{it.a};
+                    while (!st.empty() && ok) {
+                        const WideRec w = tlas[st.back()];
+                        st.pop_back();
+                        for (int c = 0; c < 2 && ok; ++c) {
+                            const uint32_t idx = bits(w.q[2 * c + 1].z), cnt = bits(w.q[2 * c + 1].w);
+                            if (cnt == 0u) st.push_back(idx);
+                            else ok = mesh_prune_ok((idx >> TLAS_REF_MESH_SHIFT) & TLAS_REF_MESH_MASK, it.b);
+                        }
+                    }
+                } else if (it.kind & ITEM_FOREST) {
+                    ok = false;  // (few-mesh kernels only)
+                } else {
+                    ok = root_count[it.a] == 0u && mesh_prune_ok(it.a, it.b);
+                }
+                if (ok) it.kind |= ITEM_PRUNE;
+            }
+            // The loop's order is free (ties between equal world distances go to the lower mesh index, rt_kernel.hip):
+            // first the meshes whose root is a leaf (the whole wave tests their triangles in step), then the other
+            // single meshes, then the trees, so that the long walks start with a closest hit to prune against.  Inside
+            // a class the order stays; an item opens its local space when its class's previous item had another one.
+            std::vector<Item> ordered;
+            for (int cls = 0; cls < 3; ++cls) {
+                bool first = true;
+                uint32_t prev_b = 0;
+                for (const Item& it0 : items) {
+                    const int c = (it0.kind & ITEM_TLAS) ? 2 : ((it0.kind & ITEM_FOREST) || root_count[it0.a] == 0u) ? 1 : 0;
+                    if (c != cls) continue;
+                    Item it = it0;
+                    it.kind &= ~(uint32_t)ITEM_NEW_XFORM;
+                    if (first || it.b != prev_b) it.kind |= ITEM_NEW_XFORM;
+                    first = false;
+                    prev_b = it.b;
+                    ordered.push_back(it);
+                }
+            }
+            // (classes follow each other: the first item of a class whose local space is the previous class's last one
+            // need not open it again)
+            for (size_t k = 1; k < ordered.size(); ++k)
+                if (ordered[k].b == ordered[k - 1].b) ordered[k].kind &= ~(uint32_t)ITEM_NEW_XFORM;
+            items.swap(ordered);
+        }
         // (one entry is always there: the many-mesh kernels, which the debug views use too,
         // run single meshes through the same stack)
         const uint32_t tlas_entries = tlas.empty() ? 1u : tlas_depth + 2u;
@@ -854,7 +909,20 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             if (m.material.flag == RT_MATERIAL_GLASS) flags |= DMESH_GLASS;
             if (deep[i]) flags |= DMESH_DEEP;
             r[8] = make_float4(asf(flags), asf(root_idx[i]), asf(root_count[i]), asf(m.triangle_offset));
-            r[9] = make_float4(asf(wide_base[i]), 0.0f, 0.0f, 0.0f);
+            {
+                // S >= the largest absolute row sum of model_to_world's 3 x 3 part ([col][row]), C >= the largest
+                // absolute translation component: in double, then rounded up (cross-mesh pruning's error terms)
+                double S = 0.0, C = 0.0;
+                for (int row = 0; row < 3; ++row) {
+                    const double rs = std::fabs((double)m.model_to_world[0][row]) + std::fabs((double)m.model_to_world[1][row]) +
+                                      std::fabs((double)m.model_to_world[2][row]);
+                    if (!(rs <= S)) S = rs;  // (NaN sticks)
+                    const double tc = std::fabs((double)m.model_to_world[3][row]);
+                    if (!(tc <= C)) C = tc;
+                }
+                auto up = [](double d) { float f = (float)d; if ((double)f < d) f = std::nextafter(f, INFINITY); return f; };
+                r[9] = make_float4(asf(wide_base[i]), up(S), up(C), 0.0f);
+            }
             const rt_node& root = nodes[m.node_offset];
             r[10] = make_float4(root.aabb_min[0], root.aabb_max[0], root.aabb_min[1], root.aabb_max[1]);
             r[11] = make_float4(root.aabb_min[2], root.aabb_max[2], 0.0f, 0.0f);
@@ -1102,6 +1170,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "cull_roots") {
         if (value < -1 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "cull_roots must be -1 (auto), 0 or 1");
         h->cull_roots = value;
+    } else if (n == "cross_prune") {
+        h->cross_prune = value ? 1 : 0;
     } else if (n == "lds_scene") {
         h->force_global = value ? 0 : 1;
     } else if (n == "defer_min_nodes") {
@@ -1236,6 +1306,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.cull_roots = (h->roots_are_unions && (h->cull_roots == 1 || (h->cull_roots < 0 && h->n_meshes >= 16))) ? 1u : 0u;
     a.many_mesh = (h->has_tlas || (a.cull_roots && !h->has_forest)) ? 1u : 0u;
     a.forest_cull = h->cull_roots != 0 ? 1u : 0u;
+    a.cross_prune = h->cross_prune != 0 ? 1u : 0u;
     {
         uint32_t ds, dv;
         memcpy(&ds, &h->camera.defocus_strength, 4);
@@ -1932,18 +2003,24 @@ static int render_multi_impl(rt_handle** per_gpu, int n_gpus, const rt_params* p
         return world == 1 ? frame_texels : rt_strip_texels(params->width, params->height, (uint32_t)r, world);
     };
     if (use_rccl) {
-        NCCL_TRY(root, g_rccl.GroupStart());
+        std::vector<GatherLeg> legs;
         for (int r = 0; r < n_gpus; ++r) {
             rt_handle* h = per_gpu[r];
-            const uint64_t n = rank_texels(r);
-            if (n == 0) continue;
-            // (each call with its communicator's device current: older RCCL releases require it in one-thread use)
-            HIP_TRY(h, hipSetDevice(h->device));
-            NCCL_TRY(root, g_rccl.Send(h->image, n * 4, ncclFloat, 0, (ncclComm_t)root->multi_comms[r], h->stream));
-            HIP_TRY(root, hipSetDevice(root->device));
-            NCCL_TRY(root, g_rccl.Recv(root->multi_gathered + (size_t)r * pad, n * 4, ncclFloat, r, (ncclComm_t)root->multi_comms[0], root->stream));
+            legs.push_back(GatherLeg{h->image, root->multi_gathered + (size_t)r * pad, (size_t)rank_texels(r) * 4, r, h->device,
+                                     (ncclComm_t)root->multi_comms[r], h->stream});
         }
-        NCCL_TRY(root, g_rccl.GroupEnd());
+        auto set_device = [](int device, std::string& err) {
+            const hipError_t e = hipSetDevice(device);
+            if (e != hipSuccess && err.empty()) err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+            return e == hipSuccess ? 0 : 1;
+        };
+        std::string gerr;
+        if (!rccl_grouped_gather(g_rccl, legs, root->device, (ncclComm_t)root->multi_comms[0], root->stream, set_device, gerr)) {
+            // the group has been closed (rt_rccl.h); a half-issued gather may have left a send without its receive on
+            // a stream: the communicators are aborted and made again by the next call
+            multi_drop_comms(root, true);
+            return fail(root, RT_ERR_DEVICE, "rt_render_multi gather: " + gerr);
+        }
         // (a rank's send is ordered on its own stream before its next render: no extra event needed)
     } else {
         for (int r = 0; r < n_gpus; ++r) {
@@ -2190,6 +2267,37 @@ int rt_test_read_wavefront(rt_handle* h, int which, void* out, uint64_t bytes) {
     HIP_TRY(h, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return RT_OK;
+}
+
+// Test-only: the grouped gather of rt_render_multi against the RCCL-shaped library at `lib_path`, on fake buffers and
+// with no HIP call (so that it runs on a machine without a GPU): n_ranks communicators from ncclCommInitAll, one
+// rccl_grouped_gather over them; on failure the communicators are aborted, as render_multi_impl does.  The error text
+// goes to rt_last_error(NULL).  tests/test_rccl_group.py drives it against tests/cpp/fake_rccl.c.
+int rt_test_rccl_gather(const char* lib_path, int n_ranks) {
+    if (!lib_path || n_ranks < 1 || n_ranks > 64) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "bad arguments");
+    RcclApi api;
+    if (!api.load(lib_path)) return fail(nullptr, RT_ERR_IO, api.why);
+    std::vector<ncclComm_t> comms((size_t)n_ranks);
+    std::vector<int> devs((size_t)n_ranks);
+    for (int r = 0; r < n_ranks; ++r) devs[(size_t)r] = r;
+    ncclResult_t r0 = api.CommInitAll(comms.data(), n_ranks, devs.data());
+    if (r0 != ncclSuccess) {
+        const std::string why = std::string("ncclCommInitAll: ") + api.GetErrorString(r0);
+        api.unload();
+        return fail(nullptr, RT_ERR_DEVICE, why);
+    }
+    static float fake_send[64][4], fake_recv[64][4];
+    std::vector<GatherLeg> legs;
+    for (int r = 0; r < n_ranks; ++r)
+        legs.push_back(GatherLeg{fake_send[r], fake_recv[r], 4, r, r, comms[(size_t)r], nullptr});
+    std::string gerr;
+    const bool ok = rccl_grouped_gather(api, legs, 0, comms[0], nullptr, [](int, std::string&) { return 0; }, gerr);
+    for (ncclComm_t c : comms) {
+        if (ok) (void)api.CommDestroy(c);
+        else api.drop(c);
+    }
+    api.unload();
+    return ok ? RT_OK : fail(nullptr, RT_ERR_DEVICE, "rt_render_multi gather: " + gerr);
 }
 
 void* rt_device_image(rt_handle* h) { return h ? (void*)h->image : nullptr; }

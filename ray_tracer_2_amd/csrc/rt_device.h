@@ -51,7 +51,10 @@ constexpr uint32_t ITEM_BYTES = 32;
 //        no stack and no loop (traverse_flat2), instead of as a forest member or a mesh walk.
 enum : uint32_t { ITEM_TLAS = 1u, ITEM_NEW_XFORM = 2u, ITEM_FOREST = 4u, ITEM_FLAT2 = 8u,
                   ITEM_DEFER = 16u,       // the big mesh whose walk a launch with RenderArgs::park != 0 defers (last item)
-                  ITEM_DEFER_CULL = 32u   // ... and its root box provably contains its children's (missing it = missing the mesh)
+                  ITEM_DEFER_CULL = 32u,  // ... and its root box provably contains its children's (missing it = missing the mesh)
+                  ITEM_PRUNE = 64u        // cross-mesh pruning may cut this item's meshes (RenderArgs::cross_prune): every mesh of the
+                                          // item has the model_to_world of the mesh that gives the local ray, bit for bit, and a BVH
+                                          // that is a proper bounding hierarchy (checked at upload, rt_api.hip)
 };
 // A top-level tree's reference to a mesh (the child index of a tree record whose child count is non-zero; with bit
 // 31 set, an entry of the tree stack): everything a lane needs to enter the mesh -- the mesh's index (the caps allow
@@ -73,7 +76,9 @@ constexpr uint32_t TLAS_MIN_MESHES = 8;
 
 // Mesh record, 12 x 16 B:
 //   q0..q3  world_to_model columns   q4..q7  model_to_world columns
-//   q8 = (flags, root_idx, root_count, tri_base)   q9 = (wide_base, 0, 0, 0)
+//   q8 = (flags, root_idx, root_count, tri_base)
+//   q9 = (wide_base, S, C, 0): S >= the largest absolute row sum of model_to_world's 3 x 3 part, C >= the largest
+//        absolute component of its translation (rounded up by the host; cross-mesh pruning's error terms)
 //   q10 = root (min.x, max.x, min.y, max.y)   q11 = root (min.z, max.z, 0, 0)
 // root_count > 0: the root is a leaf with triangles [root_idx, root_idx+count);
 // root_count == 0: root_idx is the mesh-local index of its wide record.
@@ -179,6 +184,11 @@ struct RenderArgs {
     uint32_t lds_scene;         // 1 => the blob is staged into LDS
     uint32_t forest_cull;       // 1 => forest members are skipped when the ray misses their root box
     uint32_t cull_roots;        // 1 => skip a mesh with an internal root when the ray misses the root box
+    // Cross-mesh pruning (option "cross_prune"; many-mesh product kernels): a tree box, a mesh's
+    // root box or a BVH box whose entry distance lies beyond what the closest hit so far allows -- t_cut, a local-space
+    // bound with a written error budget and 12.5 % of slack on top -- is not entered.  The counter (STATS) and debug
+    // kernels never prune.
+    uint32_t cross_prune;
     // Frame batch (rt_render_frames): one persistent launch renders frames params.frames ..
     // params.frames + batch_frames - 1; work items are (frame, tile) pairs, frame k's samples go
     // unblended to image + k * batch_stride and rt_blend_frames_kernel applies wgsl:154-161 in frame

@@ -792,6 +792,18 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
     // meshes (wgsl:369-393), as items: single meshes and top-level trees over mesh root boxes
     f3 lo{0, 0, 0}, ld{0, 0, 0}, inv{0, 0, 0};
     bool cull_ok = false;
+    // Cross-mesh pruning (many-mesh product kernels; RenderArgs::cross_prune).  The shader walks
+    // every mesh from an infinite closest distance (wgsl:292-296) and compares WORLD distances afterwards (wgsl:381-383).
+    // Here a local-space bound t_cut = closest * pa + pb is kept per local space such that a triangle hit at a local
+    // parameter t >= t_cut / 1.125 provably fails `world_dst < closest.dst` (error budget at ITEM_NEW_XFORM below); boxes
+    // whose entry distance is >= t_cut are not entered and a mesh's walk starts from t_cut instead of INF.  The counter
+    // kernels (STATS: the shader's test counts, debug views) never prune.
+    constexpr bool PRUNE = TLAS && !STATS;
+    float pa = INF, pb = INF;  // (INF, INF: no pruning -- t_cut is INF whatever the closest distance)
+    auto t_cut_of = [&](float closest) {
+        const float tc = closest * pa + pb;
+        return tc < INF ? tc : INF;  // (false for NaN and +inf)
+    };
     auto accept_hit = [&](uint32_t i, const CompactHit& b) {
         DIAG(10);
         TIC(t19);
@@ -877,6 +889,40 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             if constexpr (TLAS)
                 cull_ok = rtm::abs_(inv.x) < INF && rtm::abs_(inv.y) < INF && rtm::abs_(inv.z) < INF &&
                           rtm::abs_(lo.x) < INF && rtm::abs_(lo.y) < INF && rtm::abs_(lo.z) < INF;
+            if constexpr (PRUNE) {
+                pa = pb = INF;
+                if (a.cross_prune != 0u && cull_ok) {
+                    // The world distance the shader computes for a hit at local parameter t (world_hit: wgsl:380-381) is
+                    //   wdst_c(t) = fl|ro - fl(M (lo + ld t))|,  M = model_to_world = (A | c).
+                    // In exact arithmetic M (lo + ld t) = p0 + t g with p0 = A lo + c, g = A ld, so
+                    //   |ro - M (lo + ld t)| >= t |g| - |ro - p0|.
+                    // Rounding (u = 2^-24; S = max row sum of |A|, C = max |c_k|, L = max |lo_k|, R = max |ro_k|, |ld_k| <= 1 + 3u):
+                    //   lhp = fl(lo + fl(ld t)):  per component <= 2.1u (t + L);  whp = fl(M lhp): <= 6.2u S (L + t) + 4.1u C;
+                    //   dv = fl(ro - whp): <= 7.3u S (L + t) + 5.2u C + 1.1u R per component, sqrt(3) times that in norm;
+                    //   dot + sqrt: relative 3u.  Hence
+                    //   wdst_c(t) >= (t (|g| - 12.7u S) - |ro - p0| - 12.7u S L - 9.1u C - 2u R)(1 - 3u),
+                    // and with g, p0, the two norms evaluated in binary32 below (another 5.2u S on g, 3u relative on each
+                    // norm, 8.9u (S L + C) + 1.8u R on |ro - p0|) every term is covered by K = 2^-18 = 64u:
+                    //   wdst_c(t) > closest   for every   t >= (closest + r0 + K (S L + C + R)) / (gn (1 - K) - K S) * (1 + 3K).
+                    // t_cut is that bound times 1.125 (the slack that absorbs box / triangle inconsistencies)
+                    // times (1 + 2^-16) (the (1 + 3K) above and the roundings of pa, pb and closest * pa + pb).
+                    const float4 m0 = ld4<LDS>(a, xo + 64), m1 = ld4<LDS>(a, xo + 80), m2 = ld4<LDS>(a, xo + 96),
+                                 m3 = ld4<LDS>(a, xo + 112), aux = ld4<LDS>(a, xo + 144);
+                    const f3 g = mat_cols_xyz(m0, m1, m2, m3, ld, 0.0f);
+                    const f3 d0 = ro - mat_cols_xyz(m0, m1, m2, m3, lo, 1.0f);
+                    const float gn = rtm::sqrt_(dot3(g, g)), r0 = rtm::sqrt_(dot3(d0, d0));
+                    const float L = max_(max_(rtm::abs_(lo.x), rtm::abs_(lo.y)), rtm::abs_(lo.z));
+                    const float R = max_(max_(rtm::abs_(ro.x), rtm::abs_(ro.y)), rtm::abs_(ro.z));
+                    const float K = 0x1p-18f, F = 1.125f + 0x1.2p-16f;  // F = 1.125 (1 + 2^-16), exact
+                    const float D = gn * (1.0f - K) - K * aux.y;
+                    const float B = r0 + K * ((aux.y * L + aux.z) + R);
+                    if (D > 0.0f && B < INF) {  // (false for NaN)
+                        const float fd = F / D;
+                        pa = fd;
+                        pb = fd * B;
+                    }
+                }
+            }
             TOC(t3, 3);
         }
         if constexpr (!TLAS) if (kind & ITEM_FOREST) {
@@ -966,9 +1012,12 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
             b.t = INF;
             b.tri = 0xffffffffu;
             b.u = b.v = 0.0f;
+            // (PRUNE) may this item's meshes be cut?  (wave-uniform)
+            const bool prune_item = PRUNE && (kind & ITEM_PRUNE) != 0u;
             if ((kind & ITEM_TLAS) == 0u) {
                 bool may_hit = true;
                 const float4 hdr = ld4<LDS>(a, a.lay.item_off + it * ITEM_BYTES + 16);  // (flags, root, root count)
+                const float seed = prune_item && fbits(hdr.z) == 0u ? t_cut_of(I.closest) : INF;
                 if (a.cull_roots && fbits(hdr.z) == 0u) {
                     // Mesh-level culling that cannot change the result.  The shader
                     // never tests the root box, only its two children (wgsl:316-321) -- but the
@@ -979,7 +1028,8 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                     // monotonicity: cull_ok.)
                     const uint32_t mo = a.lay.mesh_off + ia * MESH_REC_BYTES;
                     const float4 rmin = ld4<LDS>(a, mo + 160), rmax = ld4<LDS>(a, mo + 176);
-                    may_hit = !cull_ok || aabb_dist(lo, inv, rmin, rmax, INF) < INF;
+                    // (PRUNE: ... and a root box entered at or beyond t_cut holds nothing that can win)
+                    may_hit = !cull_ok || aabb_dist(lo, inv, rmin, rmax, seed) < INF;
                     // (a culled mesh -- always one with an internal root -- still counts its two root-level tests)
                     if (STATS && !may_hit) node_tests += 2;
                 }
@@ -992,6 +1042,7 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                         cur = fbits(hdr.y);
                         cur_count = fbits(hdr.z);
                         cull = (flags & DMESH_GLASS) == 0u;
+                        b.t = seed;
                         have = true;
                     }
                 }
@@ -1035,22 +1086,41 @@ DEV Hit intersect_scene(const RenderArgs& a, f3 ro, f3 rd, uint32_t* stack, int&
                                 cur = e & TLAS_REF_ROOT_MASK;
                                 cur_count = 0;
                                 cull = (e & TLAS_REF_GLASS) == 0u;
-                                b.t = INF;
+                                b.t = prune_item ? t_cut_of(I.closest) : INF;
                                 sp = 0;
                                 have = true;
                             } else {
                                 DIAG(17);
                                 float4 q0, q1, q2, q3;
                                 load_tlas<LDS>(a, e, q0, q1, q2, q3);
-                                const bool hit_a = !cull_ok || aabb_dist(lo, inv, q0, q1, INF) < INF;
-                                const bool hit_b = !cull_ok || aabb_dist(lo, inv, q2, q3, INF) < INF;
-                                if (hit_b) {
-                                    tstack[tsp * 64] = fbits(q3.z) | (fbits(q3.w) ? 0x80000000u : 0u);
-                                    ++tsp;
-                                }
-                                if (hit_a) {
-                                    tstack[tsp * 64] = fbits(q1.z) | (fbits(q1.w) ? 0x80000000u : 0u);
-                                    ++tsp;
+                                if constexpr (PRUNE) {
+                                    // the nearer box is visited first (the order of the mesh loop is free: isect_offer
+                                    // breaks ties by mesh index), so that what lies behind a hit meets a small t_cut
+                                    const float tc = prune_item ? t_cut_of(I.closest) : INF;
+                                    const float da = aabb_dist(lo, inv, q0, q1, tc), db = aabb_dist(lo, inv, q2, q3, tc);
+                                    const bool hit_a = !cull_ok || da < INF, hit_b = !cull_ok || db < INF;
+                                    const bool a_first = da <= db;
+                                    const uint32_t ea = fbits(q1.z) | (fbits(q1.w) ? 0x80000000u : 0u);
+                                    const uint32_t eb = fbits(q3.z) | (fbits(q3.w) ? 0x80000000u : 0u);
+                                    if (a_first ? hit_b : hit_a) {
+                                        tstack[tsp * 64] = a_first ? eb : ea;
+                                        ++tsp;
+                                    }
+                                    if (a_first ? hit_a : hit_b) {
+                                        tstack[tsp * 64] = a_first ? ea : eb;
+                                        ++tsp;
+                                    }
+                                } else {
+                                    const bool hit_a = !cull_ok || aabb_dist(lo, inv, q0, q1, INF) < INF;
+                                    const bool hit_b = !cull_ok || aabb_dist(lo, inv, q2, q3, INF) < INF;
+                                    if (hit_b) {
+                                        tstack[tsp * 64] = fbits(q3.z) | (fbits(q3.w) ? 0x80000000u : 0u);
+                                        ++tsp;
+                                    }
+                                    if (hit_a) {
+                                        tstack[tsp * 64] = fbits(q1.z) | (fbits(q1.w) ? 0x80000000u : 0u);
+                                        ++tsp;
+                                    }
                                 }
                             }
                         }

@@ -3,7 +3,9 @@ assets (Dragon_80K.obj, sponza.obj, dragon_large.obj) are absent from the refere
 
 A whole oracle frame at these sizes takes minutes on the host, so each test compares SAMPLED ROWS of the full-size
 GPU frame with the oracle bit for bit (the per-pixel seed is y * W + x + |frames| * 719393, wgsl:475: a row of the
-full frame is the same computation whether or not its neighbours are rendered), checks the segment count bounds, and
+full frame is the same computation whether or not its neighbours are rendered) -- one row of EVERY 8-row strip for
+configs 3 and 4 (135 rows: each strip is a unit of the multi-GPU split and a row of 8x8 tiles of the dispatch), rows from
+every one of the 8 strip classes `strip % 8` for config 5 --, checks the segment count bounds, and
 renders the same frames once more as the 8-way strip split of config 4 / 5 (`rt_render_multi_frames` with 8 handles on
 this one device: strips `s % 8`, per-rank compact images, gather, assemble) -- which must reproduce the one-GPU frame
 bit for bit.  All options are the defaults: the automatic deferred walks (config 3 / 5) and the top-level tree
@@ -37,6 +39,12 @@ def _oracle_rows(oracle, rt, arrays, W, H, bounces, spp, rows, n_frames):
     return acc[rows], segs
 
 
+def _row_per_strip(H):
+    """One row of every 8-row strip of the frame, at a varying position inside the strip."""
+    strips = np.arange((H + 7) // 8, dtype=np.uint32)
+    return np.minimum(strips * 8 + (strips * 3) % 8, H - 1).astype(np.uint32)
+
+
 def _eight_way(rt, arrays, W, H, p, n_frames):
     """The frames through the 8-way strip split on one device: 8 handles, each its strips, gather + assemble."""
     handles = [rt.RayTracer(0, W, H) for _ in range(8)]
@@ -57,7 +65,8 @@ def test_config3_standin_at_full_size(rt, oracle):
     tr = rt.RayTracer(0, W, H)
     try:
         tr.load_scene(a)
-        rows = np.array([0, 7, 8, 333, 539, 540, 541, 700, 1079], np.uint32)
+        rows = _row_per_strip(H)
+        assert rows.size == 135
         # one frame, one launch
         p = rt.make_params(W, H, nb, spp, skybox=1, frames=0)
         tr.reset_timing()
@@ -69,7 +78,7 @@ def test_config3_standin_at_full_size(rt, oracle):
         assert W * H * spp <= s.segments <= W * H * spp * (nb + 1) and s.paths == W * H * spp
         assert np.isfinite(one).all()
         # eight accumulated frames in one launch: the automatic deferred walks engage here (8 units of work)
-        few = rows[[0, 3, 5, 8]]
+        few = rows[[0, 41, 67, 68, 134]]
         tr.write_image(np.zeros((H, W, 4), np.float32))
         tr.set_option("batch_frames", 8)
         tr.reset_timing()
@@ -101,7 +110,8 @@ def test_config4_standin_at_full_size(rt, oracle):
     tr = rt.RayTracer(0, W, H)
     try:
         tr.load_scene(a)
-        rows = np.array([0, 8, 270, 539, 540, 800, 1079], np.uint32)
+        rows = _row_per_strip(H)
+        assert rows.size == 135
         p = rt.make_params(W, H, nb, spp, skybox=1, frames=0)
         tr.reset_timing()
         tr.render(p)
@@ -111,7 +121,7 @@ def test_config4_standin_at_full_size(rt, oracle):
         assert np.array_equal(bits(one[rows]), bits(ref))
         assert W * H * spp <= s.segments <= W * H * spp * (nb + 1) and np.isfinite(one).all()
         # three accumulated frames in one launch
-        few = rows[[1, 3, 6]]
+        few = rows[[1, 33, 67, 101, 134]]
         tr.write_image(np.zeros((H, W, 4), np.float32))
         tr.render_frames(p, 3)
         acc = tr.read_image(W, H)
@@ -132,6 +142,7 @@ def test_config5_standin_at_full_size(rt, oracle):
     try:
         tr.load_scene(a)
         rows = np.array([0, 9, 500, 1079, 1080, 1081, 1500, 1700, 2000, 2159, 777, 1333], np.uint32)
+        assert set((rows // 8) % 8) == set(range(8))   # a row of every rank's share of the 8-way strip split
         p = rt.make_params(W, H, nb, spp, skybox=1, frames=0)
         tr.reset_timing()
         tr.render(p)    # (16 units of work on a 1 M-triangle mesh: the automatic deferred walks run)

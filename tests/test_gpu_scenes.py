@@ -195,6 +195,30 @@ def test_full_size_properties(rt, oracle, tracer, cornell):
     assert np.isfinite(a).all() and (a[..., :3] >= 0).all()
 
 
+def test_config2_whole_frame_accumulated(rt, oracle, tracer, cornell):
+    """BASELINE config 2 (CornellBox-Original, 1920x1080, 8 spp, 4 bounces): the WHOLE frame, frames 0..3 accumulated
+    (wgsl:154-161), bit for bit against the oracle -- every texel of the headline image, not sampled rows -- for one
+    rt_render per frame (the reference's mode, src/core/app.rs:285-340; consecutive launches pipelined) and for one
+    rt_render_frames launch.  Seed: wgsl:475."""
+    W, H, NF = 1920, 1080, 4
+    tracer.load_scene(cornell)
+    ref = np.zeros((H, W, 4), np.float32)
+    want_rays = 0
+    tracer.reset_timing()
+    for f in range(NF):
+        p = rt.make_params(W, H, 4, 8, frames=f)
+        ref, st = oracle.render(p, cornell, image=ref)
+        want_rays += st.segments
+        tracer.render(p)
+        assert np.array_equal(bits(tracer.read_image(W, H)), bits(ref)), f
+    assert tracer.stats().segments == want_rays
+    tracer.write_image(np.zeros((H, W, 4), np.float32))
+    tracer.reset_timing()
+    tracer.render_frames(rt.make_params(W, H, 4, 8, frames=0), NF)
+    assert np.array_equal(bits(tracer.read_image(W, H)), bits(ref))
+    assert tracer.stats().segments == want_rays
+
+
 def test_error_codes(rt, tracer, cornell):
     L = rt.load()
     t = rt.RayTracer(0, 64, 64)
