@@ -280,6 +280,28 @@ def main():
         tracer.set_option("pipeline", 1)   # (back to the default depth)
         extras["ms_per_frame_unoverlapped"] = statistics.median(seq)
         extras["kernel_ms_unoverlapped"] = s1.kernel_ms / max(s1.launches, 1)
+        # The reference's present loop (src/core/app.rs:285-340): render one frame, consume it, render the next -- here
+        # "consume" = wait for the frame (rt_synchronize; a host copy of the 33 MB frame over PCIe would add ~0.6 ms to
+        # every variant alike).  Nothing overlaps in such a loop, so by default a frame that finds the stream idle takes
+        # the plain in-place launch (option pipeline_when_idle = 0); with 1 it pays the pipeline's scratch image, blend
+        # kernel and event hops for nothing.
+        import numpy as np
+        present = {}
+        for name, opts in (("default", {}), ("pipeline_when_idle", {"pipeline_when_idle": 1}), ("pipeline_off", {"pipeline": 0})):
+            for k, v in opts.items():
+                tracer.set_option(k, v)
+            ts = []
+            for rep in range(3):
+                tracer.synchronize()
+                t1 = time.perf_counter()
+                for f in range(32):
+                    tracer.render(rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=1 + f))
+                    tracer.synchronize()
+                ts.append((time.perf_counter() - t1) / 32 * 1e3)
+            present[name] = statistics.median(ts)
+            tracer.set_option("pipeline", 1)
+            tracer.set_option("pipeline_when_idle", 0)
+        extras["ms_per_frame_render_then_wait"] = present
         # first frame after a camera change at full size: natural tile order, primary-ray table rebuilt
         cam_t = type(arrays.uniform.camera)
         cam0 = cam_t.from_buffer_copy(bytes(arrays.uniform.camera))
@@ -368,6 +390,10 @@ def main():
         out = {
             "metric": "Mrays/s", "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            # the figures to track across rounds: ms per frame (= ms_per_step), camera paths per second and the rays that
+            # were actually traversed (`value` also counts the primary segments served from the per-pixel memo)
+            "Mpaths/s": W * H * SPP * args.steps / elapsed / 1e6,
+            "Mrays_traversed/s": (rays - reused) / elapsed / 1e6,
             # the two launch modes under explicit names (value == value_batched when --batch > 1)
             "value_batched": mrays if frames_per_launch > 1 else None,
             "value_per_frame_launch": None if args.no_per_frame_leg else rays_pf / elapsed_pf / 1e6,

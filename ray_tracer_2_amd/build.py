@@ -92,6 +92,36 @@ def build_class_driver(force=False):
     return CLASS_DRIVER_SO
 
 
+FAKE_RCCL_SO = os.path.join(ROOT, "tests", "_build", "libfake_rccl.so")
+
+
+def build_fake_rccl(force=False):
+    """tests/cpp/fake_rccl.c: the RCCL-shaped stub that fails on request (tests/test_rccl_group.py)."""
+    src = os.path.join(ROOT, "tests", "cpp", "fake_rccl.c")
+    if not force and not _newer(FAKE_RCCL_SO, [src]):
+        return FAKE_RCCL_SO
+    os.makedirs(os.path.dirname(FAKE_RCCL_SO), exist_ok=True)
+    _run(["gcc", "-std=c11", "-O1", "-fPIC", "-shared", "-Wall", "-Wextra", src, "-o", FAKE_RCCL_SO])
+    return FAKE_RCCL_SO
+
+
+HOST_SANITIZER_DRIVER = os.path.join(ROOT, "tests", "_build", "host_sanitizer_driver")
+
+
+def build_host_sanitizer_driver(force=False):
+    """tests/cpp/host_sanitizer_driver.cpp + the host loaders (OBJ / MTL / PNG / scene / BVH, no HIP) with
+    AddressSanitizer and UndefinedBehaviorSanitizer, CPU only (tests/test_host_malformed_inputs.py)."""
+    host = [os.path.join(CSRC, "host", f) for f in ("obj_loader.cpp", "bvh.cpp", "scene.cpp", "png_decode.cpp", "scene_capi.cpp")]
+    src = os.path.join(ROOT, "tests", "cpp", "host_sanitizer_driver.cpp")
+    deps = [src, *host] + [os.path.join(CSRC, h) for h in PRODUCT_HEADERS if h.startswith("host/")] + [os.path.join(ROOT, "include", "rt_abi.h")]
+    if not force and not _newer(HOST_SANITIZER_DRIVER, deps):
+        return HOST_SANITIZER_DRIVER
+    os.makedirs(os.path.dirname(HOST_SANITIZER_DRIVER), exist_ok=True)
+    _run(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+          "-Wall", "-I", os.path.join(ROOT, "include"), src, *host, "-lz", "-o", HOST_SANITIZER_DRIVER])
+    return HOST_SANITIZER_DRIVER
+
+
 def source_hash():
     """Identity of the render kernels a profile was taken on: hash of the device sources and of this
     file (the compile flags).  profiles/latest_traffic.json carries it; bench.py only reports counter

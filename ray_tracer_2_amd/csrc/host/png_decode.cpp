@@ -78,7 +78,19 @@ uint8_t to8(uint32_t v, int depth) {
 
 }  // namespace
 
+static bool decode_png_file_impl(const std::string& path, Image& out);
+
+// (never throws: a file that cannot be decoded -- whatever the reason, an allocation that fails included -- is `false`)
 bool decode_png_file(const std::string& path, Image& out) {
+    try {
+        return decode_png_file_impl(path, out);
+    } catch (const std::exception&) {
+        out = Image();
+        return false;
+    }
+}
+
+static bool decode_png_file_impl(const std::string& path, Image& out) {
     std::ifstream f(path, std::ios::binary);
     if (!f) return false;
     std::ostringstream ss;
@@ -118,6 +130,17 @@ bool decode_png_file(const std::string& path, Image& out) {
     }
     if (!have_hdr || h.w == 0 || h.h == 0 || idat.empty()) return false;
     if (h.ctype != 0 && h.ctype != 2 && h.ctype != 3 && h.ctype != 4 && h.ctype != 6) return false;
+    // the bit depths PNG allows per colour type (anything else would index samples with undefined shifts below)
+    {
+        const int d = h.depth;
+        const bool ok = h.ctype == 0 ? (d == 1 || d == 2 || d == 4 || d == 8 || d == 16)
+                      : h.ctype == 3 ? (d == 1 || d == 2 || d == 4 || d == 8)
+                                     : (d == 8 || d == 16);
+        if (!ok || (h.interlace != 0 && h.interlace != 1)) return false;
+    }
+    // A header may claim any size: refuse what would decode to more than 512 MiB of RGBA8 (the default allocation limit
+    // of the `image` crate the reference decodes with, image 0.25: Limits::default) before anything is allocated.
+    if ((uint64_t)h.w * h.h > (512ull << 20) / 4 || idat.size() > 0x7fffffffull) return false;
     int bits = h.bpp_bits();
     // inflate
     size_t raw_cap = 0;

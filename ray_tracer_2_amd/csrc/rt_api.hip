@@ -90,8 +90,13 @@ struct rt_handle {
     // Pipelined single frames (option "pipeline"): consecutive rt_render calls sample into two or three scratch images, each
     // on an internal stream of its own, and are blended in frame order on the handle's stream, so frame k + 1's launch takes the CUs that
     // frame k's draining waves free -- every frame stays observable (rt_read_image after any call returns that frame).
-    int pipeline = 4;                                  // option "pipeline": frames in flight (0 = off, 2 .. 4; config 2: 1.51 / 1.27 / 1.23 / 1.20 ms per frame; 5 and 6: 1.25, 1.24)
+    int pipeline = -1;                                 // option "pipeline": frames in flight (0 = off, 2 .. 4, -1 = automatic_pipeline_depth(); config 2: 1.51 / 1.27 / 1.23 / 1.20 ms per frame; 5 and 6: 1.25, 1.24)
     static constexpr int PIPE_MAX = 4;                 // most frames in flight (option "pipeline")
+    // option "pipeline_when_idle" (default 0): a frame that finds the handle's stream idle -- a host that renders, reads and
+    // only then renders again, the reference's present loop -- has nothing to overlap with and takes the plain in-place
+    // launch (no scratch image, no blend kernel, no event hops); 1 = pipeline such frames too
+    int pipeline_when_idle = 0;
+    uint32_t pipe_layout[PIPE_MAX][5] = {};            // (w, h, rank, world, texels) each scratch image's padding rows were zeroed for
     hipStream_t pipe_stream[PIPE_MAX] = {};
     hipEvent_t pipe_sampled[PIPE_MAX] = {};            // frame sampled into scratch[i] (recorded on pipe_stream[i])
     hipEvent_t pipe_blended[PIPE_MAX] = {};            // ... and blended out of it (recorded on the handle's stream)
@@ -213,9 +218,14 @@ namespace {
 // The pipelined single frames (rt_handle::pipeline) keep up to four streams of a handle busy, and ROCm maps a process's
 // streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with a fifth stream in the process -- the null stream, a
 // framework's copy stream -- two of them share a queue and, if those are two of the pipeline's, their launches serialise
-// (measured: 1.30 -> 1.42 ms per frame, 1.34 -> 1.60 at two frames in flight).  Ask for eight queues unless the host
-// has set the variable itself; this only has an effect when the library is loaded before the HIP runtime initialises.
-__attribute__((constructor)) void rt2_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// (measured: 1.30 -> 1.42 ms per frame, 1.34 -> 1.60 at two frames in flight).  The library does not touch the
+// environment (the variable is the host's, read when the HIP runtime initialises: INTEGRATION.md section 3; the Python
+// package and bench.py set it before they load anything): the automatic depth is four frames in flight when the host
+// has asked for five queues or more, three otherwise (1.29 against 1.23 ms per frame on four queues).
+int automatic_pipeline_depth() {
+    const char* v = getenv("GPU_MAX_HW_QUEUES");
+    return v && atoi(v) >= 5 ? 4 : 3;
+}
 
 thread_local std::string g_err;
 
@@ -1187,8 +1197,10 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         if (value < 0 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "wavefront must be 0 (off) or 1 (whenever legal)");
         h->wavefront = value;
     } else if (n == "pipeline") {
-        if (value < 0 || value > rt_handle::PIPE_MAX) return fail(h, RT_ERR_INVALID_ARGUMENT, "pipeline must be 0 (off) or 2 .. 4 (frames in flight)");
-        h->pipeline = value == 1 ? 4 : value;
+        if (value < -1 || value > rt_handle::PIPE_MAX) return fail(h, RT_ERR_INVALID_ARGUMENT, "pipeline must be -1 (automatic), 0 (off) or 2 .. 4 (frames in flight)");
+        h->pipeline = value == 1 ? -1 : value;
+    } else if (n == "pipeline_when_idle") {
+        h->pipeline_when_idle = value ? 1 : 0;
     } else if (n == "fast_miss") {
         h->fast_miss = value ? 1 : 0;
     } else if (n == "park_levels") {
@@ -1426,9 +1438,19 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     const bool wavefront_wanted = h->wavefront != 0 && a.many_mesh != 0 && !h->any_deep && params->debug_flag == 0 && params->rays_per_pixel > 0;
     // Pipelined single frames: a plain one-frame launch (no batch, no sequence of launches).
     // S is the stream this frame's sampling launch and its bookkeeping run on.
+    if (h->pipeline < 0) h->pipeline = automatic_pipeline_depth();
     const uint32_t pipe_depth = h->pipeline >= 2 ? (uint32_t)h->pipeline : 2u;
-    const bool pipe = h->pipeline != 0 && n_batch == 0 && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
-                      !rounds && !wavefront_wanted;   // (strips too: the gather reads the image behind the blend, on the handle's stream)
+    bool pipe = h->pipeline != 0 && n_batch == 0 && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
+                !rounds && !wavefront_wanted;   // (strips too: the gather reads the image behind the blend, on the handle's stream)
+    if (pipe && h->pipeline_when_idle == 0) {
+        // Every pipelined frame ends with its blend on the handle's stream: an idle stream means no frame is in flight,
+        // i.e. this frame has nothing to overlap with (yet).  It takes the plain launch; the frames a host issues while
+        // this one runs are pipelined behind it.
+        const hipError_t q = hipStreamQuery(h->stream);
+        (void)hipGetLastError();  // (hipErrorNotReady is an answer, not a failure: do not leave it for the launchers' hipGetLastError)
+        if (q == hipSuccess) pipe = false;
+        else if (q != hipErrorNotReady) return fail(h, RT_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+    }
     const uint32_t pslot = h->pipe_seq % pipe_depth;
     hipStream_t S = h->stream;
     bool pipe_barrier = false;  // this frame rewrites shared tables (tile order, primary rays): the other stream's frame has to be done
@@ -1455,11 +1477,25 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             }
             h->pipe_scratch_texels = need_texels;
         }
-        if (!h->pipe_scratch[pslot]) HIP_TRY(h, hipMalloc((void**)&h->pipe_scratch[pslot], h->pipe_scratch_texels * sizeof(float4)));
+        if (!h->pipe_scratch[pslot]) {
+            HIP_TRY(h, hipMalloc((void**)&h->pipe_scratch[pslot], h->pipe_scratch_texels * sizeof(float4)));
+            h->pipe_layout[pslot][4] = 0u;  // (nothing zeroed yet)
+        }
         S = h->pipe_stream[pslot];
         // this frame's scratch image is free once the frame before last has been blended out of it; the tables the last
         // bookkeeping frame rewrote are complete; whatever the handle's stream did outside the pipeline is complete
         if (h->pipe_blended_set[pslot]) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_blended[pslot], 0));
+        {
+            // The blend covers all need_texels, the sampling launch writes the pixels of the frame only: the padding rows of
+            // a ragged last strip (world > 1, height % 8 != 0) must blend as zeros, as in the batch path -- a fresh
+            // allocation, or samples an earlier frame of another shape left there, would otherwise reach the strip
+            // buffer's padding rows (the assembled frame never reads them).
+            const uint32_t key[5] = {params->width, params->height, rank, world, (uint32_t)need_texels};
+            if (memcmp(h->pipe_layout[pslot], key, sizeof(key)) != 0) {
+                HIP_TRY(h, hipMemsetAsync(h->pipe_scratch[pslot], 0, need_texels * sizeof(float4), S));
+                memcpy(h->pipe_layout[pslot], key, sizeof(key));
+            }
+        }
         if (h->pipe_book_set) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_book, 0));
         if (h->pipe_main_set) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_main, 0));
         if (a.pixel_cache == 2u && pslot != 0u) {   // the global-memory memo is per resident wave: one per concurrent launch
@@ -2140,6 +2176,9 @@ int rt_reset_timing(rt_handle* h) {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(Counters), h->stream));
+    // (a pipelined frame's sampling launch runs on an internal stream that is not ordered behind this stream's
+    // memset: the zeroing is complete before the call returns, so no later launch's counter adds can race with it)
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->ev_used = 0;
     h->ev_ms_harvested = 0.0;
     h->launches_total = h->frames_total = 0;

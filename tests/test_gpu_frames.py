@@ -173,6 +173,38 @@ def test_strip_frames_assemble_to_the_full_frames(rt, tracer, cornell, sponza, s
     stage.close()
 
 
+def test_raw_strip_buffers_agree_between_the_launch_paths(rt, cornell):
+    """A rank's raw strip buffer -- the padding rows of a ragged last strip included (height % 8 != 0: they are what the
+    gather ships, the assembled frame never reads them) -- is the same whether its frames were rendered in place
+    (pipeline off), through the pipeline's scratch images or as one batch, also right after frames of another shape
+    went through the same scratch images."""
+    w, h, spp, nb, n, world = 200, 100, 2, 3, 4, 3   # 13 strips: rank 0 owns the ragged last one (rows 96..99 of 104)
+    t = rt.RayTracer(0, 256, 128)
+    try:
+        t.load_scene(cornell)
+        cnt = t.strip_texels(w, h, 0, world)
+        got = {}
+        for mode in ("plain", "pipeline", "batch"):
+            t.set_option("pipeline", 0 if mode == "plain" else 4)
+            t.set_option("pipeline_when_idle", 1)
+            if mode == "pipeline":   # dirty the scratch images with full frames of another shape first
+                for f in range(4):
+                    t.render(rt.make_params(256, 128, 2, 1, skybox=1, frames=f))
+            t.write_image(np.zeros((128, 256, 4), np.float32))
+            if mode == "batch":
+                t.render_strips_frames(rt.make_params(w, h, nb, spp, skybox=1, frames=0), n, 0, world)
+            else:
+                for f in range(n):
+                    t.render_strips(rt.make_params(w, h, nb, spp, skybox=1, frames=f), 0, world)
+            got[mode] = t.read_texels(cnt).copy()
+        assert np.array_equal(bits(got["plain"]), bits(got["pipeline"]))
+        assert np.array_equal(bits(got["plain"]), bits(got["batch"]))
+        # the padding rows stay what the host wrote there (zeros): nobody samples them
+        assert not got["plain"].reshape(-1, w, 4)[-4:].any()
+    finally:
+        t.close()
+
+
 @pytest.mark.parametrize("batch", [1, 4, "rccl"])
 def test_bench_rank_plumbing_on_torch_memory_and_stream(batch):
     """What `bench.py --gpus N` does per rank, all ranks in one process: every rank renders its strips straight into a
@@ -385,14 +417,19 @@ def test_pipelined_single_frames(rt, oracle, tracer, cornell):
     try:
         tracer.set_option("pipeline", 0)
         want = script(tracer)
-        for depth in (2, 3, 4):   # frames in flight
+        # (pipeline_when_idle = 1: frames this small are over before the next call arrives, and a frame that finds the
+        # stream idle takes the plain launch by default -- here every frame goes through the pipeline; the last run is
+        # the default rule, whichever way each frame goes)
+        for depth, when_idle in ((2, 1), (3, 1), (4, 1), (4, 0)):   # frames in flight
             tracer.set_option("pipeline", depth)
+            tracer.set_option("pipeline_when_idle", when_idle)
             got = script(tracer)
             assert len(got) == len(want)
             for k, (g, wnt) in enumerate(zip(got, want)):
-                assert np.array_equal(bits(g), bits(wnt)), (depth, k)
+                assert np.array_equal(bits(g), bits(wnt)), (depth, when_idle, k)
     finally:
         tracer.set_option("pipeline", 1)
+        tracer.set_option("pipeline_when_idle", 0)
     ref = np.zeros((h, w, 4), np.float32)
     for f in range(3):
         ref, _ = oracle.render(rt.make_params(w, h, 4, 3, skybox=1, frames=f), cornell, image=ref)
@@ -408,6 +445,7 @@ def test_pipelined_single_frames_global_memory_scene(rt, tracer):
         tracer.load_scene(arrays)
         outs = []
         try:
+            tracer.set_option("pipeline_when_idle", 1)   # (every frame through the pipeline, see above)
             for pipe in (0, 3, 4):
                 tracer.set_option("pipeline", pipe)
                 tracer.write_image(np.zeros((h, w, 4), np.float32))
@@ -417,5 +455,6 @@ def test_pipelined_single_frames_global_memory_scene(rt, tracer):
                 outs.append((tracer.read_image(w, h).copy(), tracer.stats().segments))
         finally:
             tracer.set_option("pipeline", 1)
+            tracer.set_option("pipeline_when_idle", 0)
         for o in outs[1:]:
             assert np.array_equal(bits(outs[0][0]), bits(o[0])) and outs[0][1] == o[1]
