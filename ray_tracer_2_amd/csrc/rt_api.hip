@@ -28,7 +28,7 @@ hipError_t launch_render(const RenderArgs& a, hipStream_t stream);
 size_t render_lds_bytes(const RenderArgs& a);
 hipError_t launch_tile_order(const uint32_t* cost, uint32_t n_tiles, uint32_t max_cost, uint32_t* order,
                              hipStream_t stream);
-hipError_t launch_primary(const RenderArgs& a, float* table, hipStream_t stream);
+hipError_t launch_primary(const RenderArgs& a, void* table, bool with_hits, hipStream_t stream);
 hipError_t launch_blend_frames(const BlendArgs& b, hipStream_t stream);
 hipError_t launch_walk(const RenderArgs& a, uint32_t compute_units, hipStream_t stream);
 hipError_t launch_wf_shade(const RenderArgs& a, uint32_t blocks, hipStream_t stream);
@@ -168,13 +168,17 @@ struct rt_handle {
     int cost_slot = 0;
     bool history_valid = false;
     uint32_t hist_w = 0, hist_h = 0, hist_rank = 0, hist_world = 0;
-    // primary-ray table (rt_primary_kernel): valid for (camera, width, height)
-    float* primary = nullptr;
+    // primary table (rt_primary_kernel): every pixel's memo -- its constant primary ray and (option "primary_hits") that
+    // ray's hit -- valid for (camera, width, height, strip layout, scene, with / without hits); 64 B per pixel
+    void* primary = nullptr;
     size_t primary_texels = 0;
     bool primary_valid = false;
     rt_camera_uniform primary_camera{};
-    uint32_t primary_w = 0, primary_h = 0;
+    uint32_t primary_w = 0, primary_h = 0, primary_rank = 0, primary_world = 0;
+    bool primary_with_hits = false;
     int use_primary = 1;  // option "primary_table"
+    int primary_hits = 1; // option "primary_hits": the table also holds the primary rays' hits, so that the frames of an
+                          // accumulation (still camera, src/core/app.rs:44-53) traverse no primary ray at all
     int tile_feedback = 1;
     int tile_feedback_period = 8;  // frames an order is kept before it is refreshed
     bool have_order = false, costs_ready = false;
@@ -1091,6 +1095,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->camera = scene->camera;
         h->have_scene = true;
         h->history_valid = false;
+        h->primary_valid = false;  // (the table holds hits: a function of the scene)
     } catch (const std::bad_alloc&) {
         return fail(h, RT_ERR_OUT_OF_MEMORY, "out of host memory");
     }
@@ -1152,6 +1157,9 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         h->history_valid = false;
     } else if (n == "primary_table") {
         h->use_primary = value ? 1 : 0;
+    } else if (n == "primary_hits") {
+        h->primary_hits = value ? 1 : 0;
+        h->primary_valid = false;
     } else if (n == "tile_feedback_period") {
         if (value < 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "tile_feedback_period must be >= 1");
         h->tile_feedback_period = value;
@@ -1525,18 +1533,27 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         const size_t texels = (size_t)((params->width + 7) / 8) * ((params->height + 7) / 8) * 64;  // whole 8x8 tiles
         if (h->primary_texels < texels) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));
+            for (int k = 0; k < rt_handle::PIPE_MAX; ++k)   // (pipelined frames read the table on their own streams)
+                if (h->pipe_stream[k]) HIP_TRY(h, hipStreamSynchronize(h->pipe_stream[k]));
             free_dev(h->primary);
-            HIP_TRY(h, hipMalloc((void**)&h->primary, texels * 3 * sizeof(float)));
+            HIP_TRY(h, hipMalloc((void**)&h->primary, texels * 64));
             h->primary_texels = texels;
             h->primary_valid = false;
         }
+        // (the counter kernels re-intersect every segment, so a launch with counters neither needs nor fills the hits)
+        const bool with_hits = h->primary_hits != 0 && a.count_tests == 0u;
         if (!h->primary_valid || h->primary_w != params->width || h->primary_h != params->height ||
+            h->primary_rank != rank || h->primary_world != world || (with_hits && !h->primary_with_hits) ||
             memcmp(&h->primary_camera, &h->camera, sizeof(rt_camera_uniform)) != 0) {
             HIP_TRY(h, barrier_other());
-            HIP_TRY(h, launch_primary(a, h->primary, S));
+            a.primary = nullptr;
+            HIP_TRY(h, launch_primary(a, h->primary, with_hits, S));
             h->primary_valid = true;
             h->primary_w = params->width;
             h->primary_h = params->height;
+            h->primary_rank = rank;
+            h->primary_world = world;
+            h->primary_with_hits = with_hits;
             h->primary_camera = h->camera;
         }
         a.primary = h->primary;

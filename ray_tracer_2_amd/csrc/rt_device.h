@@ -170,7 +170,8 @@ struct RenderArgs {
     uint32_t pixel_cache;    // per-lane primary-ray memo (PIXEL_MEMO_DWORDS per lane): 0 off, 1 in LDS,
                              // 2 in `pixel_cache_mem` (persistent kernel only, when LDS has no room)
     uint32_t* pixel_cache_mem;
-    const float* primary;    // primary-ray table of the frame (rt_primary_kernel: 3 floats per pixel), or null: compute per pixel
+    const void* primary;     // primary table of the frame (rt_primary_kernel: one 64-byte memo entry per pixel -- the constant
+                             // primary ray and, with option "primary_hits", its hit), or null: compute per pixel
     float spp_reciprocal;     // 1 / rays_per_pixel when that is a power of two (exact), else 0
     float blend_weight, blend_rest;  // 1 / f32(frames + 1) and 1 - that (wgsl:157-158)
     float memo_ro[3];        // (origin + right * 0) + up * 0: the memoised primary rays' common origin

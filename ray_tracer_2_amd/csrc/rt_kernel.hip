@@ -1481,19 +1481,25 @@ DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts&
     f3 rd;
     const uint32_t y = frame_row_of(ca, s.out_row);
     if (a.primary) {
-        // camera and frame size have not changed since rt_primary_kernel filled the table: the same
-        // values, computed there with every lane busy instead of here with a handful
-        // (12 bytes per pixel; a NaN x marks "not constant": a constant ray that is NaN itself then
-        // merely takes the per-sample path, which computes the same NaN)
-        // table order = the order in which lanes take pixels (8x8 tile by tile, row-major inside): the
-        // lanes refilled together read neighbouring entries
-        const __attribute__((address_space(1))) float* v =
-            (const __attribute__((address_space(1))) float*)a.primary + primary_index(ca.params.width, s.x, y) * 3u;
-        rd = f3{v[0], v[1], v[2]};
-        constant_ray = rd.x == rd.x;
-    } else {
-        rd = memo_ray_of<SQ>(ca, c, s.x, y, constant_ray);
+        // Camera, frame size and scene have not changed since rt_primary_kernel filled the table: the pixel's whole memo
+        // -- its constant primary ray and, with option "primary_hits", that ray's hit (a pure function of the ray and
+        // the scene) -- computed there once, with every lane busy, instead of here with a handful and again in every
+        // frame of the accumulation.  One 64-byte entry per pixel (the memo's 13 dwords, see path_begin), in the order in
+        // which lanes take pixels (8x8 tile by tile, row-major inside): the lanes refilled together read neighbouring
+        // entries.  Same inputs, same operations, same bits as the per-sample path.
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // (a plain vector: global_load_dwordx4 through the typed pointer)
+        const __attribute__((address_space(1))) u32x4* v =
+            (const __attribute__((address_space(1))) u32x4*)a.primary + primary_index(ca.params.width, s.x, y) * 4u;
+        const u32x4 e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+        with_memo<WF>(a, ls, [&](auto pc) {
+            pc[0] = e0.x; pc[64] = e0.y; pc[2 * 64] = e0.z; pc[3 * 64] = e0.w;
+            pc[4 * 64] = e1.x; pc[5 * 64] = e1.y; pc[6 * 64] = e1.z; pc[7 * 64] = e1.w;
+            pc[8 * 64] = e2.x; pc[9 * 64] = e2.y; pc[10 * 64] = e2.z; pc[11 * 64] = e2.w;
+            pc[12 * 64] = e3.x;
+        });
+        return;
     }
+    rd = memo_ray_of<SQ>(ca, c, s.x, y, constant_ray);
     with_memo<WF>(a, ls, [&](auto pc) {
         pc[0] = __float_as_uint(rd.x); pc[64] = __float_as_uint(rd.y); pc[128] = __float_as_uint(rd.z);
         pc[12 * 64] = constant_ray ? MEMO_RAY : 0u;
@@ -2787,22 +2793,41 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rt_debug_kernel(const RenderArg
     }
 }
 
-// Scatter gathered strips (rank-major, each rank padded to `pad_texels`) into
-// the full frame: strip s of the frame is local strip s / world of rank
-// s % world.
-// Primary-ray table: (direction, constant-ray flag) of every pixel of the frame, for the memo of
-// the render kernels.  Depends on the camera and the frame size only, so progressive accumulation
-// computes it once.
-__global__ void __launch_bounds__(256) rt_primary_kernel(const RenderArgs a, float* __restrict__ table) {
-    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
-    if (x >= a.params.width || y >= a.params.height) return;
+// Primary table: the memo of every pixel of the launch's tiles (the rank's strips) -- the pixel's constant primary ray
+// and, when `with_hits`, that ray's hit: what path_begin / memo_hit_store would put into the lane's memo the first time
+// a sample of the pixel is traced, computed once per (camera, frame size, scene) instead of once per pixel and frame.
+// The ray comes from memo_ray_of (the operations of wgsl:479-495 with the zero-strength jitter folded, see path_begin),
+// the hit from intersect_scene with the origin every memoised ray shares (RenderArgs::memo_ro).  One wave per 8x8 tile,
+// launched with the render launch's arguments and LDS size.
+template <bool LDS, bool TLAS>
+__global__ void __launch_bounds__(BLOCK_THREADS) rt_primary_kernel(const RenderArgs a, uint4* __restrict__ table, uint32_t with_hits) {
+    uint32_t* stack = stack_of<total_in_lds(LDS)>(block_prologue<LDS>(a));
+    const uint32_t tile = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (tile >= a.tiles_x * a.tiles_y) return;
+    const PixelCoord px = pixel_of(a, tile, threadIdx.x & 63u);
+    if (!px.valid) return;
     const CameraConsts c = camera_consts(a);
     bool constant_ray;
-    const f3 rd = memo_ray_of(a, c, x, y, constant_ray);
-    float* t = table + primary_index(a.params.width, x, y) * 3u;
-    t[0] = constant_ray ? rd.x : __uint_as_float(0x7fc00000u);
-    t[1] = rd.y;
-    t[2] = rd.z;
+    const f3 rd = memo_ray_of(a, c, px.x, px.y, constant_ray);
+    uint32_t word = constant_ray ? MEMO_RAY : 0u;
+    Hit hit;
+    hit.hit = false;
+    hit.backface = false;
+    hit.dst = 0.0f;
+    hit.point = hit.normal = f3{0, 0, 0};
+    hit.u = hit.v = 0.0f;
+    hit.mat_off = 0u;
+    if (constant_ray && with_hits != 0u) {
+        int s0 = 0, s1 = 0;
+        Isect unused;
+        hit = intersect_scene<LDS, false, TLAS>(a, f3{a.memo_ro[0], a.memo_ro[1], a.memo_ro[2]}, rd, stack, s0, s1, unused);
+        word = (hit.hit ? (hit.mat_off & ~15u) | MEMO_HIT : 0u) | (hit.backface ? MEMO_BACKFACE : 0u) | MEMO_RAY | MEMO_HIT_VALID;
+    }
+    uint4* e = table + primary_index(a.params.width, px.x, px.y) * 4u;
+    e[0] = make_uint4(__float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z), __float_as_uint(hit.dst));
+    e[1] = make_uint4(__float_as_uint(hit.point.x), __float_as_uint(hit.point.y), __float_as_uint(hit.point.z), __float_as_uint(hit.normal.x));
+    e[2] = make_uint4(__float_as_uint(hit.normal.y), __float_as_uint(hit.normal.z), __float_as_uint(hit.u), __float_as_uint(hit.v));
+    e[3] = make_uint4(word, 0u, 0u, 0u);
 }
 
 // wgsl:154-161 for the frames of a batch, in frame order: the only dependency between frames is
@@ -2829,6 +2854,9 @@ __global__ void __launch_bounds__(256) rt_blend_frames_kernel(const BlendArgs b)
     if (have) b.image[i] = acc;
 }
 
+// Scatter gathered strips (rank-major, each rank padded to `pad_texels`) into
+// the full frame: strip s of the frame is local strip s / world of rank
+// s % world.
 __global__ void rt_assemble_kernel(const float4* __restrict__ gathered, float4* __restrict__ image,
                                    uint32_t width, uint32_t height, uint32_t world,
                                    unsigned long long pad_texels) {
@@ -3099,9 +3127,23 @@ hipError_t launch_units_texture(const uint8_t* rgba8, uint32_t width, uint32_t h
     return hipGetLastError();
 }
 
-hipError_t launch_primary(const RenderArgs& a, float* table, hipStream_t stream) {
-    if (a.params.width == 0 || a.params.height == 0) return hipSuccess;
-    hipLaunchKernelGGL(rt_primary_kernel, dim3((a.params.width + 63u) / 64u, (a.params.height + 3u) / 4u), dim3(256), 0, stream, a, table);
+hipError_t launch_primary(const RenderArgs& a, void* table, bool with_hits, hipStream_t stream) {
+    const uint32_t ntiles = a.tiles_x * a.tiles_y;
+    if (ntiles == 0) return hipSuccess;
+    const size_t lds = render_lds_bytes(a);
+    const uint32_t blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    auto go = [&](auto kernel) {
+        if (lds > 64u * 1024u) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), lds, stream, a, (uint4*)table, with_hits ? 1u : 0u);
+    };
+    const bool tlas = a.many_mesh != 0;
+    if (a.lds_scene) {
+        if (tlas) go(rt_primary_kernel<true, true>);
+        else go(rt_primary_kernel<true, false>);
+    } else {
+        if (tlas) go(rt_primary_kernel<false, true>);
+        else go(rt_primary_kernel<false, false>);
+    }
     return hipGetLastError();
 }
 

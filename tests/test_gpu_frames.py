@@ -82,28 +82,85 @@ def test_render_frames_with_the_stats_counters(rt, oracle, tracer, cornell):
 @pytest.mark.parametrize("variant,lds,batch", [(0, 1, 0), (1, 1, 0), (0, 0, 0), (1, 0, 0), (0, 1, 6), (0, 0, 6)])
 def test_segments_reused_is_exact(rt, tracer, cornell, variant, lds, batch):
     """rt_stats.segments_reused (segments served from the primary-ray memo): with the zero-strength Cornell camera every
-    pixel's primary ray is constant (no -0 involved at an even width), so every sample but a pixel's first takes its
-    primary hit from the memo: exactly W * H * (spp - 1) per frame, whichever kernel renders the frame and however
-    many lanes of a wave sit out an iteration."""
+    pixel's primary ray is constant (no -0 involved at an even width) and its hit is in the primary table (option
+    primary_hits: computed once per camera, size and scene), so EVERY primary segment takes its hit from the memo: exactly
+    W * H * spp per frame, whichever kernel renders the frame and however many lanes of a wave sit out an iteration.
+    Without the hits in the table (primary_hits = 0) a pixel's first sample of every frame traverses: W * H * (spp - 1).
+    The ray count is the same either way."""
     w, h, spp, frames = 200, 104, 5, 6
     tracer.load_scene(cornell)
     tracer.set_option("kernel_variant", variant)
     tracer.set_option("lds_scene", lds)
+    got = {}
     try:
-        tracer.reset_timing()
-        if batch:
-            tracer.set_option("batch_frames", batch)
-            tracer.render_frames(rt.make_params(w, h, 4, spp, skybox=1, frames=0), frames)
-        else:
-            for f in range(frames):
-                tracer.render(rt.make_params(w, h, 4, spp, skybox=1, frames=f))
-        s = tracer.stats()
+        for hits in (1, 0):
+            tracer.set_option("primary_hits", hits)
+            tracer.reset_timing()
+            if batch:
+                tracer.set_option("batch_frames", batch)
+                tracer.render_frames(rt.make_params(w, h, 4, spp, skybox=1, frames=0), frames)
+            else:
+                for f in range(frames):
+                    tracer.render(rt.make_params(w, h, 4, spp, skybox=1, frames=f))
+            got[hits] = (tracer.stats(), tracer.read_image(w, h).copy())
     finally:
         tracer.set_option("kernel_variant", -1)
         tracer.set_option("lds_scene", 1)
         tracer.set_option("batch_frames", 16)
-    assert s.segments_reused == w * h * (spp - 1) * frames
-    assert s.paths == w * h * spp * frames and s.segments - s.segments_reused >= w * h * frames
+        tracer.set_option("primary_hits", 1)
+    s, s0 = got[1][0], got[0][0]
+    assert s.segments_reused == w * h * spp * frames and s0.segments_reused == w * h * (spp - 1) * frames
+    assert s.segments == s0.segments and np.array_equal(bits(got[1][1]), bits(got[0][1]))
+    assert s.paths == w * h * spp * frames and s0.segments - s0.segments_reused >= w * h * frames
+
+
+def test_primary_table_follows_camera_scene_and_strip_layout(rt, oracle, cornell):
+    """The primary table (every pixel's constant primary ray and its hit) is a function of camera, frame size, strip
+    layout and scene: each of them changing between frames -- with pipelined frames in flight -- must rebuild it; the
+    frames equal the oracle's throughout.  (A stale table would show the old camera's or the old scene's first hits.)"""
+    w, h = 136, 80
+    t = rt.RayTracer(0, w, h)
+    try:
+        t.set_option("pipeline_when_idle", 1)
+        t.load_scene(cornell)
+
+        def check(arrays, frames, width=w, height=h):
+            ref = np.zeros((height, width, 4), np.float32)
+            for f in range(frames):
+                p = rt.make_params(width, height, 3, 2, skybox=1, frames=f)
+                ref, _ = oracle.render(p, arrays, image=ref)
+                t.render(p)
+            assert np.array_equal(bits(t.read_image(width, height)), bits(ref))
+        check(cornell, 3)
+        cam_t = type(cornell.uniform.camera)
+        moved = rt.SceneArrays(cornell.uniform, cornell.spheres, cornell.meshes, cornell.triangles, cornell.nodes)
+        moved.uniform = type(cornell.uniform).from_buffer_copy(bytes(cornell.uniform))
+        moved.uniform.camera.cam_to_world[3][0] += 0.21
+        t.set_camera(cam_t.from_buffer_copy(bytes(moved.uniform.camera)))      # camera: new rays, new hits
+        check(moved, 2)
+        tris = cornell.triangles.copy()                                        # scene: same rays, new hits
+        tris["v1"][:, 1] += 0.05
+        tris["v2"][:, 1] += 0.05
+        tris["v3"][:, 1] += 0.05
+        lifted = rt.SceneArrays(moved.uniform, cornell.spheres, cornell.meshes, tris, cornell.nodes)
+        nodes = cornell.nodes.copy()
+        nodes["aabb_min"][:, 1] += 0.05
+        nodes["aabb_max"][:, 1] += 0.05
+        lifted = rt.SceneArrays(moved.uniform, cornell.spheres, cornell.meshes, tris, nodes)
+        t.update_buffers(lifted)
+        check(lifted, 2)
+        check(lifted, 2, 96, 56)                                               # frame size
+        # strip layout: rank 1 of 3 after the full frame, against the rows of the full frame
+        full = t.read_image(96, 56).copy()
+        t.write_image(np.zeros((h, w, 4), np.float32))
+        for f in range(2):
+            t.render_strips(rt.make_params(96, 56, 3, 2, skybox=1, frames=f), 1, 3)
+        cnt = t.strip_texels(96, 56, 1, 3)
+        mine = t.read_texels(cnt).reshape(-1, 96, 4)
+        rows = [s * 8 + r for s in range(7) if s % 3 == 1 for r in range(8)]
+        assert np.array_equal(bits(mine[:len(rows)]), bits(full[rows]))
+    finally:
+        t.close()
 
 
 @pytest.mark.parametrize("kw", [dict(lds_scene=0), dict(pixel_cache=0), dict(pixel_cache=2), dict(tile_feedback=0), dict(batch_tile_major=0)])
