@@ -302,13 +302,14 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 the others, 8 and 16 inside a deferred-walk sequence)
  *   tile_feedback         0 / 1 (1)               order the tiles by an earlier frame's rays per tile, heaviest first
  *   tile_feedback_period  >= 1 (8)                frames an order is kept before it is refreshed
- *   pipeline              -1 / 0 / 2 / 3 / 4 (-1) frames in flight: consecutive rt_render calls sample into that many scratch images,
+ *   pipeline              -1 / 0 / 2 .. 8 (-1)    frames in flight: consecutive rt_render calls sample into that many scratch images,
  *                                                 each on an internal stream of its own, and are blended in frame order on the
  *                                                 handle's stream: frame k + 1's launch takes the CUs frame k's draining waves free;
  *                                                 every frame stays observable (config 2: 1.51 / 1.27 / 1.23 / 1.20 ms per frame at
  *                                                 0 / 2 / 3 / 4, config 3 stand-in 7.26 / 6.83 at 3 / 4).  Needs a hardware queue per
  *                                                 stream: -1 (and 1) = four frames when the host has set GPU_MAX_HW_QUEUES >= 5, three
- *                                                 otherwise (the library never touches the environment)
+ *                                                 otherwise; seven for a rank of a strip split of 4 ranks and more when there are
+ *                                                 8 queues (the library never touches the environment)
  *   pipeline_when_idle    0 / 1 (0)               1 = also pipeline a frame that finds the handle's stream idle; by default such a
  *                                                 frame -- a host that renders, reads, renders: nothing to overlap with -- takes the
  *                                                 plain in-place launch (no scratch image, no blend kernel)

@@ -91,7 +91,7 @@ struct rt_handle {
     // on an internal stream of its own, and are blended in frame order on the handle's stream, so frame k + 1's launch takes the CUs that
     // frame k's draining waves free -- every frame stays observable (rt_read_image after any call returns that frame).
     int pipeline = -1;                                 // option "pipeline": frames in flight (0 = off, 2 .. 4, -1 = automatic_pipeline_depth(); config 2: 1.51 / 1.27 / 1.23 / 1.20 ms per frame; 5 and 6: 1.25, 1.24)
-    static constexpr int PIPE_MAX = 4;                 // most frames in flight (option "pipeline")
+    static constexpr int PIPE_MAX = 8;                 // most frames in flight (option "pipeline")
     // option "pipeline_when_idle" (default 0): a frame that finds the handle's stream idle -- a host that renders, reads and
     // only then renders again, the reference's present loop -- has nothing to overlap with and takes the plain in-place
     // launch (no scratch image, no blend kernel, no event hops); 1 = pipeline such frames too
@@ -225,10 +225,15 @@ namespace {
 // (measured: 1.30 -> 1.42 ms per frame, 1.34 -> 1.60 at two frames in flight).  The library does not touch the
 // environment (the variable is the host's, read when the HIP runtime initialises: INTEGRATION.md section 3; the Python
 // package and bench.py set it before they load anything): the automatic depth is four frames in flight when the host
-// has asked for five queues or more, three otherwise (1.29 against 1.23 ms per frame on four queues).
-int automatic_pipeline_depth() {
+// has asked for five queues or more, three otherwise (1.29 against 1.23 ms per frame on four queues).  A rank of a
+// strip split whose share no longer fills the machine (world >= 4: 518 K pixels and fewer for 328 K resident lanes) runs
+// seven frames deep when there are eight queues: a frame's latency is then set by its longest pixel chain, not by its
+// work (rank 0's share of config 2 at world 8: 0.226 -> 0.207 ms per frame; profiles/r04_strip_pipeline_depth.txt).
+int automatic_pipeline_depth(uint32_t world) {
     const char* v = getenv("GPU_MAX_HW_QUEUES");
-    return v && atoi(v) >= 5 ? 4 : 3;
+    const int queues = v ? atoi(v) : 4;
+    if (world >= 4 && queues >= 8) return 7;
+    return queues >= 5 ? 4 : 3;
 }
 
 thread_local std::string g_err;
@@ -1205,7 +1210,7 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         if (value < 0 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "wavefront must be 0 (off) or 1 (whenever legal)");
         h->wavefront = value;
     } else if (n == "pipeline") {
-        if (value < -1 || value > rt_handle::PIPE_MAX) return fail(h, RT_ERR_INVALID_ARGUMENT, "pipeline must be -1 (automatic), 0 (off) or 2 .. 4 (frames in flight)");
+        if (value < -1 || value > rt_handle::PIPE_MAX) return fail(h, RT_ERR_INVALID_ARGUMENT, "pipeline must be -1 (automatic), 0 (off) or 2 .. 8 (frames in flight)");
         h->pipeline = value == 1 ? -1 : value;
     } else if (n == "pipeline_when_idle") {
         h->pipeline_when_idle = value ? 1 : 0;
@@ -1446,9 +1451,9 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     const bool wavefront_wanted = h->wavefront != 0 && a.many_mesh != 0 && !h->any_deep && params->debug_flag == 0 && params->rays_per_pixel > 0;
     // Pipelined single frames: a plain one-frame launch (no batch, no sequence of launches).
     // S is the stream this frame's sampling launch and its bookkeeping run on.
-    if (h->pipeline < 0) h->pipeline = automatic_pipeline_depth();
-    const uint32_t pipe_depth = h->pipeline >= 2 ? (uint32_t)h->pipeline : 2u;
-    bool pipe = h->pipeline != 0 && n_batch == 0 && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
+    const int pipeline_opt = h->pipeline < 0 ? automatic_pipeline_depth(world) : h->pipeline;
+    const uint32_t pipe_depth = pipeline_opt >= 2 ? (uint32_t)pipeline_opt : 2u;
+    bool pipe = pipeline_opt != 0 && n_batch == 0 && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
                 !rounds && !wavefront_wanted;   // (strips too: the gather reads the image behind the blend, on the handle's stream)
     if (pipe && h->pipeline_when_idle == 0) {
         // Every pipelined frame ends with its blend on the handle's stream: an idle stream means no frame is in flight,
@@ -1463,7 +1468,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     hipStream_t S = h->stream;
     bool pipe_barrier = false;  // this frame rewrites shared tables (tile order, primary rays): the other stream's frame has to be done
     if (pipe) {
-        h->pipe_seq = (h->pipe_seq + 1) % 12u;   // (a multiple of every depth)
+        h->pipe_seq = (h->pipe_seq + 1) % 840u;   // (a multiple of every depth)
         for (int k = 0; k < (int)pipe_depth; ++k) {   // (no more streams than frames in flight: they share the process's hardware queues)
             if (!h->pipe_stream[k]) HIP_TRY(h, hipStreamCreateWithFlags(&h->pipe_stream[k], hipStreamNonBlocking));
             if (!h->pipe_sampled[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_sampled[k], hipEventDisableTiming));

@@ -19,8 +19,8 @@ tr = rt.RayTracer(0, W, H)
 tr.load_scene(arrays)
 base = {}
 # (mode, frames per launch, option pipeline): wall time per frame -- pipelined launches overlap, their event times do not add up
-for mode, batch, pipe in (("one launch per frame, no pipeline", 1, 0), ("one launch per frame, pipelined (default)", 1, 4),
-                          ("32 frames per launch", 32, 4)):
+for mode, batch, pipe in (("one launch per frame, no pipeline", 1, 0), ("one launch per frame, four frames in flight", 1, 4),
+                          ("one launch per frame, pipelined (default depth)", 1, -1), ("32 frames per launch", 32, -1)):
     tr.set_option("batch_frames", batch)
     tr.set_option("pipeline", pipe)
     for world in (1, 2, 4, 8):
@@ -35,4 +35,4 @@ for mode, batch, pipe in (("one launch per frame, no pipeline", 1, 0), ("one lau
         t = statistics.median(ts)
         if world == 1:
             base[mode] = t
-        print(f"{mode:42s} world {world}: {t:.3f} ms per frame for rank 0's share -> compute-only speed-up {base[mode] / t:.2f}x", flush=True)
+        print(f"{mode:48s} world {world}: {t:.3f} ms per frame for rank 0's share -> compute-only speed-up {base[mode] / t:.2f}x", flush=True)
