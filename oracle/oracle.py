@@ -104,6 +104,17 @@ def max_stack_index(reset=True):
     return int(L.oracle_max_stack_index(C.c_int(1 if reset else 0)))
 
 
+def census(enable):
+    """Census of triangle hits against the entry distance of their leaf boxes (shader_oracle.cpp census_hit; the
+    hypothesis behind the product's cross-mesh pruning, DESIGN.md 2.4).  census(True) switches it on and clears it;
+    census(False) switches it off and returns what was counted since."""
+    L = load()
+    out = (C.c_double * 7)()
+    L.oracle_census(C.c_int(1 if enable else 0), out)
+    keys = ("hits", "entry_gt_t", "gt_1e-6", "gt_1e-4", "gt_1pct", "gt_12.5pct", "max_ratio")
+    return dict(zip(keys, out))
+
+
 def rng_sequence(seed, n):
     L = load()
     s = C.c_uint32(seed)

@@ -276,6 +276,30 @@ static inline float ray_aabb_dist(const Ray& ray, vec3 b_min, vec3 b_max, float 
 // wgsl:292-335.  Out-of-range stack indices are clamped (naga "Restrict").
 static thread_local uint32_t g_max_stack_index = 0;  // oracle-only: lets tests see that the stack overflowed
 
+// Oracle-only census for the hypothesis behind the product's cross-mesh pruning: for every
+// triangle test that reports a hit, how the hit's parameter t compares with the entry distance the slab test computes
+// for the LEAF box that holds the triangle (the boxes above it can only be entered earlier: nested boxes have nested
+// slab intervals).  In exact arithmetic entry <= t; the pruning is exact as long as entry <= 1.125 t.
+static std::atomic<int> g_census_on{0};
+static std::atomic<uint64_t> g_census[6];            // hits, entry > t, > t (1 + 1e-6), > t (1 + 1e-4), > 1.01 t, > 1.125 t
+static std::atomic<uint32_t> g_census_max_bits{0};   // largest entry / t seen (float bits; ratios are positive)
+static inline float ray_aabb_dist(const Ray& ray, vec3 b_min, vec3 b_max, float t);
+static void census_hit(const Ray& ray, const rt_node& leaf, float t) {
+    const float entry = ray_aabb_dist(ray, vec3{leaf.aabb_min[0], leaf.aabb_min[1], leaf.aabb_min[2]},
+                                      vec3{leaf.aabb_max[0], leaf.aabb_max[1], leaf.aabb_max[2]}, INF);
+    g_census[0].fetch_add(1, std::memory_order_relaxed);
+    if (!(entry < INF) || !(entry > t)) return;   // (a root leaf's box is never tested by the shader: it may be missed)
+    const float ratio = entry / t;
+    g_census[1].fetch_add(1, std::memory_order_relaxed);
+    if (ratio > 1.0f + 1e-6f) g_census[2].fetch_add(1, std::memory_order_relaxed);
+    if (ratio > 1.0f + 1e-4f) g_census[3].fetch_add(1, std::memory_order_relaxed);
+    if (ratio > 1.01f) g_census[4].fetch_add(1, std::memory_order_relaxed);
+    if (ratio > 1.125f) g_census[5].fetch_add(1, std::memory_order_relaxed);
+    uint32_t bits, old = g_census_max_bits.load(std::memory_order_relaxed);
+    memcpy(&bits, &ratio, 4);
+    while (bits > old && !g_census_max_bits.compare_exchange_weak(old, bits, std::memory_order_relaxed)) {}
+}
+
 static Hit ray_BVH(const Ctx& c, const Ray& ray, float ray_length, uint32_t node_offset,
                    uint32_t tri_offset, bool cull_backface, int32_t stats[2]) {
     Hit closest_hit;
@@ -294,6 +318,7 @@ static Hit ray_BVH(const Ctx& c, const Ray& ray, float ray_length, uint32_t node
             for (uint32_t j = 0u; j < node.count; j += 1u) {
                 const rt_packed_triangle& tri = c.triangles[tri_offset + node.first + j];
                 Hit hit = ray_triangle(ray, tri, cull_backface);
+                if (hit.hit && g_census_on.load(std::memory_order_relaxed)) census_hit(ray, node, hit.dst);
                 if (hit.hit && hit.dst < closest_hit.dst) {
                     closest_hit = hit;
                     closest_hit.tri = (int)(tri_offset + node.first + j);
@@ -657,6 +682,23 @@ uint32_t oracle_max_stack_index(int reset) {
     uint32_t v = orc::g_max_stack_index;
     if (reset) orc::g_max_stack_index = 0;
     return v;
+}
+
+// Census of triangle hits against their leaf boxes (see census_hit): enable != 0 switches it on and clears it, 0 switches
+// it off; out[7] = {hits, entry > t, > t (1 + 1e-6), > t (1 + 1e-4), > 1.01 t, > 1.125 t, largest entry / t}.
+void oracle_census(int enable, double out[7]) {
+    if (out) {
+        for (int k = 0; k < 6; ++k) out[k] = (double)orc::g_census[k].load();
+        float m;
+        const uint32_t b = orc::g_census_max_bits.load();
+        memcpy(&m, &b, 4);
+        out[6] = m;
+    }
+    if (enable) {
+        for (auto& c : orc::g_census) c.store(0);
+        orc::g_census_max_bits.store(0);
+    }
+    orc::g_census_on.store(enable ? 1 : 0);
 }
 
 uint32_t oracle_next_random_number(uint32_t* state) { return orc::next_random_number(state); }

@@ -339,7 +339,7 @@ void multi_drop_comms(rt_handle* root, bool abort = false) {
 
 extern "C" {
 
-const char* rt_version(void) { return "ray_tracer_2_amd 0.1 (gfx950)"; }
+const char* rt_version(void) { return RT_EXPERIMENTS ? "ray_tracer_2_amd 0.1 (gfx950) +experiments" : "ray_tracer_2_amd 0.1 (gfx950)"; }
 
 int rt_device_count(void) {
     int n = 0;
@@ -993,7 +993,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         SceneLayout sl{};
         uint32_t small_need = 1;
         bool small_ok = false;
-        if (have_defer) {
+        if (RT_EXPERIMENTS && have_defer) {
             const uint32_t d = defer_mesh;
             bool last = wide_base[d] + defer_internal == (uint32_t)wide.size();
             for (uint32_t i = 0; i < n_meshes; ++i)
@@ -1203,6 +1203,10 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "sort_rounds") {
         if (value < -1 || value > 64) return fail(h, RT_ERR_INVALID_ARGUMENT, "sort_rounds must be -1 (automatic), 0 (off) or 1 .. 64");
         h->sort_rounds = value;
+    } else if (!RT_EXPERIMENTS && (n == "lds_top" || n == "wavefront" || n == "hybrid" || n == "lds_tlas")) {
+        // (0 = "off" is what this build does anyway: scripts that reset their options keep working)
+        if (value != 0) return fail(h, RT_ERR_INVALID_ARGUMENT, "option " + n + " belongs to the measured-slower experiments: "
+                                    "build with -DRT_EXPERIMENTS=1 (tools/build_variant.sh exp -DRT_EXPERIMENTS=1)");
     } else if (n == "lds_top") {
         if (value < -1 || value > 2048) return fail(h, RT_ERR_INVALID_ARGUMENT, "lds_top must be -1 (auto), 0 (off) or a record count <= 2048");
         h->lds_top = value;
@@ -1327,7 +1331,10 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     }
     a.blob = h->blob;
     a.lay = h->lay;
-    a.lds_scene = (h->lds_scene && !h->force_global) ? 1u : 0u;
+    // (an explicitly requested deferred-walk sequence -- option "sort_rounds" > 0, tests -- reads the scene in place: the
+    // parking instantiations exist for global-memory scenes only; the automatic setting never defers a mesh of a scene
+    // that fits the LDS)
+    a.lds_scene = (h->lds_scene && !h->force_global && !(h->sort_rounds > 0 && h->have_defer)) ? 1u : 0u;
     a.cull_roots = (h->roots_are_unions && (h->cull_roots == 1 || (h->cull_roots < 0 && h->n_meshes >= 16))) ? 1u : 0u;
     a.many_mesh = (h->has_tlas || (a.cull_roots && !h->has_forest)) ? 1u : 0u;
     a.forest_cull = h->cull_roots != 0 ? 1u : 0u;
@@ -1364,6 +1371,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.kernel_variant = h->kernel_variant >= 0 ? (uint32_t)h->kernel_variant
                                               : ((uint64_t)a.tiles_x * a.tiles_y * 4 <= (uint64_t)resident_waves * 5 ? 1u : 0u);
     if (n_batch) a.kernel_variant = 0;  // (frame, tile) work items are the persistent kernel's
+    if (a.count_tests) a.kernel_variant = 0;  // (the counter instantiations exist for the persistent kernel only)
     // (all fields that size the LDS are set by now)
     a.pixel_cache = 0;
     a.pixel_cache_mem = nullptr;
@@ -1375,14 +1383,14 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     // records as fit beside the stacks without costing a workgroup per CU, or what option "lds_top" says
     a.top_base = h->top_base;
     a.top_count = 0;
-    if (!a.lds_scene && h->top_available && h->lds_top != 0) {
+    if (RT_EXPERIMENTS && !a.lds_scene && h->top_available && h->lds_top != 0) {
         const size_t used = render_lds_bytes(a);
         uint32_t fit = used < LDS_BUDGET_BYTES ? (uint32_t)((LDS_BUDGET_BYTES - used) / WIDE_REC_BYTES) : 0u;
         if (h->lds_top > 0) fit = (uint32_t)h->lds_top;
         a.top_count = std::min(fit, h->top_available);
     }
     a.tlas_lds = 0;
-    if (!a.lds_scene && a.many_mesh && h->has_tlas && h->lds_tlas != 0 && params->debug_flag == 0) {
+    if (RT_EXPERIMENTS && !a.lds_scene && a.many_mesh && h->has_tlas && h->lds_tlas != 0 && params->debug_flag == 0) {
         // 1: as many of the breadth-first numbered records (the top levels first) as fit without costing a workgroup per
         // CU; 2: the whole tree if the LDS can hold it at all
         const size_t used = render_lds_bytes(a), need = (size_t)h->n_tlas_records * WIDE_REC_BYTES;
@@ -1436,7 +1444,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         }
     }
     bool rounds = n_rounds > 0 && h->have_defer && a.many_mesh == 0 && a.kernel_variant == 0 && params->debug_flag == 0 &&
-                  params->rays_per_pixel > 0;
+                  params->rays_per_pixel > 0 && a.lds_scene == 0u;
     // The intersection vote (path_begin).  The more a traversal costs beside the rest of an iteration, the longer it pays
     // to let the lanes on memoised primary segments catch up first: 6/8 of the lanes or 3 iterations when the scene is in
     // LDS and walked by the few-mesh kernels (config 2: 1.221 ms per frame; 1.222 with 7/8 and 16, 1.366 with 8/8), 7/8 or
@@ -1448,7 +1456,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         a.vote_eighths = h->vote_eighths >= 0 ? (uint32_t)h->vote_eighths : rounds ? 8u : costly ? 7u : 6u;
         a.vote_patience = h->vote_patience >= 0 ? (uint32_t)h->vote_patience : (rounds || costly) ? 16u : 3u;
     }
-    const bool wavefront_wanted = h->wavefront != 0 && a.many_mesh != 0 && !h->any_deep && params->debug_flag == 0 && params->rays_per_pixel > 0;
+    const bool wavefront_wanted = RT_EXPERIMENTS && h->wavefront != 0 && a.many_mesh != 0 && !h->any_deep && params->debug_flag == 0 && params->rays_per_pixel > 0;
     // Pipelined single frames: a plain one-frame launch (no batch, no sequence of launches).
     // S is the stream this frame's sampling launch and its bookkeeping run on.
     const int pipeline_opt = h->pipeline < 0 ? automatic_pipeline_depth(world) : h->pipeline;
@@ -1588,7 +1596,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     const uint64_t wf_slots64 = (uint64_t)wf_frame_slots * (n_batch ? n_batch : 1u);
     const uint64_t wf_rounds64 = params->number_of_bounces < 0 ? 0ull
         : (uint64_t)(params->rays_per_pixel > 0 ? params->rays_per_pixel : 0) * ((uint64_t)params->number_of_bounces + 1ull);
-    bool wavefront = h->wavefront != 0 && a.many_mesh != 0 && !h->any_deep && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
+    bool wavefront = RT_EXPERIMENTS && h->wavefront != 0 && a.many_mesh != 0 && !h->any_deep && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
                      params->width <= 0xffffu && params->height <= 0xffffu && wf_slots64 < (1ull << 31) && wf_rounds64 <= 1024ull;
     const size_t wf_bytes_per_slot = (WF_STATE_PLANES + WF_HIT_PLANES) * sizeof(float4) + 2 * sizeof(uint32_t) + PIXEL_MEMO_DWORDS * sizeof(uint32_t);
     if (wavefront && h->wf_capacity < wf_slots64) {
@@ -1821,7 +1829,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         // the big mesh reads its shading record from the full blob.  The last launch (park = 0) and rt_walk_kernel
         // read the full blob as before.
         RenderArgs ah = a;
-        bool hybrid = h->hybrid != 0 && h->small_ok && !a.lds_scene && a.count_tests == 0 && a.kernel_variant == 0;
+        bool hybrid = RT_EXPERIMENTS && h->hybrid != 0 && h->small_ok && !a.lds_scene && a.count_tests == 0 && a.kernel_variant == 0;
         if (hybrid) {
             ah.blob = h->small_blob;
             ah.lay = h->small_lay;

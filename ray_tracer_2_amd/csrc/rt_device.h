@@ -11,6 +11,15 @@
 
 #include "../../include/rt_abi.h"
 
+// Features that were built, parity-tested and measured SLOWER than what ships -- the LDS-staged top of a big mesh's BVH
+// (option "lds_top"), the LDS-staged top-level tree ("lds_tlas"), the hybrid launches of a deferred-walk sequence
+// ("hybrid") and the wavefront sequence ("wavefront"); measurements in DESIGN.md sections 5.4 / 5.5 -- are compiled only
+// with -DRT_EXPERIMENTS=1 (tools/build_variant.sh exp -DRT_EXPERIMENTS=1 -> librt2_mi355x_exp.so; their parity tests run
+// against that build: RT2_LIB=... pytest).  The product library contains none of their kernels and rejects the options.
+#ifndef RT_EXPERIMENTS
+#define RT_EXPERIMENTS 0
+#endif
+
 namespace rtd {
 
 // The whole scene is one blob of 16-byte words, either read in place (global

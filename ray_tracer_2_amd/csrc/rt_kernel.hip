@@ -252,43 +252,48 @@ DEV int ldi(const RenderArgs& a, uint32_t byte_off) {
 }
 DEV uint32_t fbits(float f) { return __float_as_uint(f); }
 
+// Built-and-measured-slower features (LDS-staged BVH / tree tops, hybrid launches, the wavefront sequence: DESIGN.md
+// sections 5.4, 5.5) are only compiled with -DRT_EXPERIMENTS=1 (tools/build_variant.sh exp -DRT_EXPERIMENTS=1); the
+// product library has none of their code.
+#if RT_EXPERIMENTS
 // float4 offset of the LDS-staged BVH top (global-memory kernels): behind the wave regions and cost tables
 DEV uint32_t top_lds_off16(const RenderArgs& a);
+DEV uint32_t tlas_lds_off16(const RenderArgs& a);
+#endif
 
-// The wide record `idx` (absolute index): from the staged scene, from the LDS-staged top of the big
-// mesh's BVH, or from global memory.
+// The wide record `idx` (absolute index): from the staged scene or from global memory (RT_EXPERIMENTS: or from the
+// LDS-staged top of the big mesh's BVH, option "lds_top").
 template <bool LDS>
 DEV void load_wide(const RenderArgs& a, uint32_t idx, float4& q0, float4& q1, float4& q2, float4& q3) {
-    if constexpr (LDS) {
-        const uint32_t wo = a.lay.wide_off + idx * WIDE_REC_BYTES;
-        q0 = ld4<true>(a, wo); q1 = ld4<true>(a, wo + 16); q2 = ld4<true>(a, wo + 32); q3 = ld4<true>(a, wo + 48);
-    } else {
+#if RT_EXPERIMENTS
+    if constexpr (!LDS) {
         const uint32_t rel = idx - a.top_base;
         if (rel < a.top_count) {
             const float4* p = lds_mem + top_lds_off16(a) + rel * 4u;
             q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-        } else {
-            const uint32_t wo = a.lay.wide_off + idx * WIDE_REC_BYTES;
-            q0 = ld4<false>(a, wo); q1 = ld4<false>(a, wo + 16); q2 = ld4<false>(a, wo + 32); q3 = ld4<false>(a, wo + 48);
+            return;
         }
     }
+#endif
+    const uint32_t wo = a.lay.wide_off + idx * WIDE_REC_BYTES;
+    q0 = ld4<LDS>(a, wo); q1 = ld4<LDS>(a, wo + 16); q2 = ld4<LDS>(a, wo + 32); q3 = ld4<LDS>(a, wo + 48);
 }
 
-// Top-level tree record `e` (many-mesh kernels): from the staged scene, from the LDS-staged copy of the tree
-// (RenderArgs::tlas_lds: scenes read from global memory whose tree fits beside the stacks), or from global memory.
-DEV uint32_t tlas_lds_off16(const RenderArgs& a);
+// Top-level tree record `e` (many-mesh kernels): from the staged scene or from global memory (RT_EXPERIMENTS: or from
+// the LDS-staged copy of the tree, option "lds_tlas").
 template <bool LDS>
 DEV void load_tlas(const RenderArgs& a, uint32_t e, float4& q0, float4& q1, float4& q2, float4& q3) {
-    if constexpr (LDS) {
-        const uint32_t wo = a.lay.tlas_off + e * WIDE_REC_BYTES;
-        q0 = ld4<true>(a, wo); q1 = ld4<true>(a, wo + 16); q2 = ld4<true>(a, wo + 32); q3 = ld4<true>(a, wo + 48);
-    } else if (e < a.tlas_lds) {  // (the first tlas_lds records -- the top levels, numbered breadth-first -- are staged)
-        const float4* p = lds_mem + tlas_lds_off16(a) + e * 4u;
-        q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-    } else {
-        const uint32_t wo = a.lay.tlas_off + e * WIDE_REC_BYTES;
-        q0 = ld4<false>(a, wo); q1 = ld4<false>(a, wo + 16); q2 = ld4<false>(a, wo + 32); q3 = ld4<false>(a, wo + 48);
+#if RT_EXPERIMENTS
+    if constexpr (!LDS) {
+        if (e < a.tlas_lds) {  // (the first tlas_lds records -- the top levels, numbered breadth-first -- are staged)
+            const float4* p = lds_mem + tlas_lds_off16(a) + e * 4u;
+            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+            return;
+        }
     }
+#endif
+    const uint32_t wo = a.lay.tlas_off + e * WIDE_REC_BYTES;
+    q0 = ld4<LDS>(a, wo); q1 = ld4<LDS>(a, wo + 16); q2 = ld4<LDS>(a, wo + 32); q3 = ld4<LDS>(a, wo + 48);
 }
 
 // (mat4 * vec4(v, w)).xyz with the four columns as float4
@@ -1291,8 +1296,10 @@ DEV uint32_t wave_region_dwords(const RenderArgs& a) {
            stack_dwords(a) + a.tlas_entries * 64u;
 }
 
+#if RT_EXPERIMENTS
 DEV uint32_t top_lds_off16(const RenderArgs& a) { return (WAVES_PER_BLOCK * wave_region_dwords(a) + WAVES_PER_BLOCK * 8u * 3u) >> 2; }
 DEV uint32_t tlas_lds_off16(const RenderArgs& a) { return top_lds_off16(a) + a.top_count * 4u; }
+#endif
 
 // Stage the scene blob into LDS (coalesced 16-byte loads, whole workgroup) and
 // return this lane's base pointer (its lane state; see the map above).
@@ -1304,7 +1311,9 @@ DEV uint32_t* block_prologue(const RenderArgs& a) {
         for (uint32_t i = threadIdx.x; i < n16; i += BLOCK_THREADS) lds_mem[i] = a.blob[i];
         __syncthreads();
         base = n16;
-    } else if (a.top_count != 0u || a.tlas_lds != 0u) {
+    }
+#if RT_EXPERIMENTS
+    else if (a.top_count != 0u || a.tlas_lds != 0u) {
         // the top of the big mesh's BVH: top_count consecutive wide records
         const uint32_t src = (a.lay.wide_off + a.top_base * WIDE_REC_BYTES) >> 4, dst = top_lds_off16(a);
         for (uint32_t i = threadIdx.x; i < a.top_count * 4u; i += BLOCK_THREADS) lds_mem[dst + i] = a.blob[src + i];
@@ -1313,6 +1322,7 @@ DEV uint32_t* block_prologue(const RenderArgs& a) {
         for (uint32_t i = threadIdx.x; i < a.tlas_lds * 4u; i += BLOCK_THREADS) lds_mem[tdst + i] = a.blob[tsrc + i];
         __syncthreads();
     }
+#endif
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     return reinterpret_cast<uint32_t*>(lds_mem + base) + wave * wave_region_dwords(a) +
            (a.pixel_cache == 1u ? PIXEL_MEMO_DWORDS * 64u : 0u) + lane;
@@ -2294,6 +2304,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderA
     }
 }
 
+#if RT_EXPERIMENTS
 // ---------------------------------------------------------------------------
 // Wavefront sequence (RenderArgs::wf_*, rt_device.h): the path state of every pixel of the launch lives in a slot in
 // global memory; rt_wf_shade_kernel runs everything of path_step but the traversal, rt_wf_walk_kernel runs the
@@ -2708,6 +2719,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_wf_walk_kernel
     }
 }
 
+#endif  // RT_EXPERIMENTS (wavefront sequence)
+
 // ---------------------------------------------------------------------------
 // wgsl debug_trace (wgsl:502-573): one primary ray, no RNG.
 // ---------------------------------------------------------------------------
@@ -2938,8 +2951,11 @@ size_t render_lds_bytes(const RenderArgs& a) {
     size_t lane_state = total_in_lds(a.lds_scene != 0u) ? (size_t)LANE_STATE_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
     size_t cache = a.pixel_cache == 1u ? (size_t)PIXEL_MEMO_DWORDS * 64u * sizeof(uint32_t) * WAVES_PER_BLOCK : 0u;
     // (= 4 x wave_region_dwords + the cost tables, see the LDS map)
-    return stacks + cost_tables + lane_state + cache +
-           (a.lds_scene ? a.lay.bytes : ((size_t)a.top_count + a.tlas_lds) * WIDE_REC_BYTES);
+    size_t scene = a.lds_scene ? a.lay.bytes : 0u;
+#if RT_EXPERIMENTS
+    if (!a.lds_scene) scene = ((size_t)a.top_count + a.tlas_lds) * WIDE_REC_BYTES;
+#endif
+    return stacks + cost_tables + lane_state + cache + scene;
 }
 
 // Dynamic LDS above 64 KiB (deep-BVH stacks) has to be opted into per kernel.
@@ -2950,6 +2966,12 @@ static void launch_k(K kernel, uint32_t blocks, size_t lds, hipStream_t stream, 
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), lds, stream, a);
 }
 
+// Which instantiations exist (the product library; every one of them is what some BASELINE config or test runs):
+//   persistent <LDS | global> x <few-mesh: general, SIMPLE, counters | many-mesh: general, counters>   = 10
+//   + the deferred-walk launches, global-memory few-mesh scenes only: general, SIMPLE, counters            =  3
+//   one wave per tile (small launches) <LDS | global> x <few-mesh: general, SIMPLE | many-mesh: general> =  6
+// Counter launches always take the persistent kernel; a scene that fits the LDS has no mesh worth deferring (the host
+// never asks: rt_api.hip render_impl).  -DRT_EXPERIMENTS=1 adds the hybrid launches and the wavefront kernels.
 template <bool LDS, bool TLAS>
 static void launch_variant(const RenderArgs& a, uint32_t ntiles, size_t lds, hipStream_t stream) {
     const uint32_t tile_blocks = (ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
@@ -2957,21 +2979,26 @@ static void launch_variant(const RenderArgs& a, uint32_t ntiles, size_t lds, hip
     const bool simple = !TLAS && a.simple != 0u && a.count_tests == 0u;
     if (a.params.debug_flag != 0) {
         launch_k(rt_debug_kernel<LDS, TLAS>, tile_blocks, lds, stream, a);
-    } else if (a.kernel_variant == 1) {
-        if (a.count_tests) launch_k(rt_render_tiles_kernel<LDS, true, TLAS, false>, tile_blocks, lds, stream, a);
-        else if (simple) launch_k(rt_render_tiles_kernel<LDS, false, TLAS, !TLAS>, tile_blocks, lds, stream, a);
+    } else if (a.kernel_variant == 1 && a.count_tests == 0u) {
+        if (simple) launch_k(rt_render_tiles_kernel<LDS, false, TLAS, !TLAS>, tile_blocks, lds, stream, a);
         else launch_k(rt_render_tiles_kernel<LDS, false, TLAS, false>, tile_blocks, lds, stream, a);
     } else {
         uint32_t blocks = a.persistent_blocks < tile_blocks ? a.persistent_blocks : tile_blocks;
         if (blocks == 0) blocks = 1;
-        const bool park = !TLAS && (a.park != 0u || a.q_in != nullptr);  // a launch of a deferred-walk sequence
+        // a launch of a deferred-walk sequence (PARK): few-mesh scenes read from global memory
+        constexpr bool CAN_PARK = !TLAS && !LDS;
+        const bool park = CAN_PARK && (a.park != 0u || a.q_in != nullptr);
+#if RT_EXPERIMENTS
+        if (LDS && !TLAS && (a.park != 0u || a.q_in != nullptr)) {  // (host: hybrid launches only -- the small blob is staged)
+            if (simple) launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS, !TLAS, LDS && !TLAS>, blocks, lds, stream, a);
+            else launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS, false, LDS && !TLAS>, blocks, lds, stream, a);
+            return;
+        }
+#endif
         if (park) {
-            if (LDS && !TLAS && a.hybrid != 0u && a.count_tests == 0u) {  // (host: only launches that park)
-                if (simple) launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS, !TLAS, LDS && !TLAS>, blocks, lds, stream, a);
-                else launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS, false, LDS && !TLAS>, blocks, lds, stream, a);
-            } else if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS, !TLAS, false>, blocks, lds, stream, a);
-            else if (simple) launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS, !TLAS>, blocks, lds, stream, a);
-            else launch_k(rt_render_persistent_kernel<LDS, false, TLAS, !TLAS, false>, blocks, lds, stream, a);
+            if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS, CAN_PARK, false>, blocks, lds, stream, a);
+            else if (simple) launch_k(rt_render_persistent_kernel<LDS, false, TLAS, CAN_PARK, CAN_PARK>, blocks, lds, stream, a);
+            else launch_k(rt_render_persistent_kernel<LDS, false, TLAS, CAN_PARK, false>, blocks, lds, stream, a);
         } else {
             if (a.count_tests) launch_k(rt_render_persistent_kernel<LDS, true, TLAS, false, false>, blocks, lds, stream, a);
             else if (simple) launch_k(rt_render_persistent_kernel<LDS, false, TLAS, false, !TLAS>, blocks, lds, stream, a);
@@ -3011,6 +3038,7 @@ hipError_t launch_walk(const RenderArgs& a, uint32_t compute_units, hipStream_t 
     return hipGetLastError();
 }
 
+#if RT_EXPERIMENTS
 // the two kernels of a wavefront sequence (persistent grids; a launch whose list is empty ends at once)
 size_t wf_walk_lds_bytes(const RenderArgs& a) {
     return ((size_t)(a.stack_entries ? a.stack_entries : 1u) * (a.stack_wide ? 128u : 64u) + (size_t)a.tlas_entries * 64u) * sizeof(uint32_t) * WAVES_PER_BLOCK;
@@ -3028,6 +3056,15 @@ hipError_t launch_wf_walk(const RenderArgs& a, uint32_t blocks, hipStream_t stre
     else launch_k(rt_wf_walk_kernel<false>, blocks, lds, stream, a);
     return hipGetLastError();
 }
+
+#endif
+
+#if !RT_EXPERIMENTS
+// (the host never gets here in the product build: option "wavefront" cannot be switched on)
+size_t wf_walk_lds_bytes(const RenderArgs&) { return 0; }
+hipError_t launch_wf_shade(const RenderArgs&, uint32_t, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_wf_walk(const RenderArgs&, uint32_t, hipStream_t) { return hipErrorNotSupported; }
+#endif
 
 hipError_t launch_blend_frames(const BlendArgs& b, hipStream_t stream) {
     if (b.texels == 0 || b.n == 0) return hipSuccess;

@@ -51,3 +51,11 @@ def tracer(rt):
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def experiments_build():
+    """True when the loaded library was built with -DRT_EXPERIMENTS=1 (tools/build_variant.sh exp -DRT_EXPERIMENTS=1, then
+    RT2_LIB=ray_tracer_2_amd/librt2_mi355x_exp.so pytest ...): the measured-slower features -- options lds_top, lds_tlas,
+    hybrid, wavefront -- only exist there; the product library rejects the options."""
+    import ray_tracer_2_amd
+    return b"+experiments" in ray_tracer_2_amd.load().rt_version()

@@ -89,7 +89,11 @@ def main():
     rgb = slice(0, 4)
     d_same = (m64 - m32).mean((0, 1))
     d_other = (m64 - m32o).mean((0, 1))
-    z = np.abs(m64 - m32o) / np.maximum(np.sqrt(2.0) * se_pixel, 1e-12)
+    # per pixel, disjoint seeds: the deterministic pixels (the ones that look past the box: the same sky sample every
+    # frame) must simply agree.  (No per-pixel z-score for the others: the light is small and the shader samples it by
+    # chance only, so a pixel's 256 samples are far too heavy-tailed for their own variance estimate to mean anything.)
+    noisy = se_pixel[..., :3] > 1e-9
+    det_rel = (np.abs(m64 - m32o) / np.maximum(np.abs(m32o), 1e-3))[..., :3]
     out["converged"] = {
         "channel_mean_f64": m64.mean((0, 1)).tolist(),
         "channel_mean_f32_same_seeds": m32.mean((0, 1)).tolist(),
@@ -103,7 +107,8 @@ def main():
         "converged_pixels_within_1e-5_same_seeds": agree(m64, m32),
         "converged_pixels_within_1e-3_same_seeds": agree(m64, m32, 1e-3),
         "converged_max_relative_diff_same_seeds": float((np.abs(m64 - m32) / np.maximum(np.abs(m32), 1e-3))[..., rgb].max()),
-        "disjoint_seeds_pixels_beyond_4_sigma": float((z[..., :3] > 4.0).mean()),
+        "disjoint_seeds_noisy_channel_fraction": float(noisy.mean()),
+        "disjoint_seeds_deterministic_channels_max_rel_diff": float(det_rel[~noisy].max()) if (~noisy).any() else 0.0,
         "progressive_accumulation_f32_vs_f64_mean_of_its_samples_max_rel": float((np.abs(acc - m32) / np.maximum(np.abs(m32), 1e-3)).max()),
     }
     path = os.path.join(ROOT, "tests", "golden", "f64_pin.json")

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ROOT, bits
+from conftest import experiments_build,  ROOT, bits
 
 pytestmark = pytest.mark.gpu
 DATA = os.path.join(ROOT, "tests", "data")
@@ -411,7 +411,8 @@ def test_random_many_mesh_scenes(rt, oracle, tracer, seed):
 
 @pytest.mark.parametrize("knobs", [{"forest": 0}, {"stack_wide": 1}, {"stack_wide": 0}, {"pixel_cache": 0}, {"pixel_cache": 2}, {"primary_table": 0},
                                    {"forest": 0, "stack_wide": 1, "pixel_cache": 2},
-                                   {"lds_top": -1}, {"lds_top": 1}, {"lds_top": 77}, {"lds_top": 2048}, {"flat2": 0}, {"flat2": 0, "forest": 0},
+                                   {"lds_top": -1}, {"lds_top": 1}, {"lds_top": 77}, {"lds_top": 2048},   # (experiments build only)
+                                   {"flat2": 0}, {"flat2": 0, "forest": 0},
                                    {"specialise": 0}, {"specialise": 0, "kernel_variant": 1}, {"specialise": 1, "kernel_variant": 1},
                                    {"fast_miss": 0}, {"fast_miss": 0, "kernel_variant": 1}, {"vote_eighths": 8, "vote_patience": 16},
                                    {"vote_eighths": 0}, {"vote_eighths": 7, "vote_patience": 0}],
@@ -422,6 +423,10 @@ def test_tuning_knobs_do_not_change_the_bits(rt, oracle, tracer, cornell, dragon
     global-memory dragon scene."""
     defaults = {"forest": 1, "stack_wide": -1, "pixel_cache": 1, "primary_table": 1, "lds_top": 0, "flat2": 1, "specialise": 1,
                 "kernel_variant": -1, "fast_miss": 1, "vote_eighths": -1, "vote_patience": -1}
+    if "lds_top" in knobs and not experiments_build():
+        with pytest.raises(rt.RtError):   # the product library has no such code and says so
+            tracer.set_option("lds_top", knobs["lds_top"])
+        pytest.skip("option lds_top needs the -DRT_EXPERIMENTS=1 build")
     try:
         for name, value in knobs.items():
             tracer.set_option(name, value)
@@ -505,8 +510,8 @@ def test_deferred_walks_do_not_change_the_bits(rt, oracle, tracer, dragon_arrays
         tracer.set_counters(False)
         # option hybrid = 1: the parking launches stage everything but the big mesh into LDS (and only a winner on the big
         # mesh reads its shading record from global memory) instead of reading the whole scene in place -- the same bits
-        tracer.set_option("hybrid", 1)
-        for rounds in (2, 5):
+        tracer.set_option("hybrid", 1 if experiments_build() else 0)
+        for rounds in (2, 5) if experiments_build() else ():
             tracer.set_option("sort_rounds", rounds)
             tracer.write_image(np.zeros((H, W, 4), np.float32))
             tracer.render_frames(p, 3)
@@ -719,7 +724,7 @@ def test_config4_sponza_sized_standin(rt, oracle, tracer):
     tracer.set_option("tlas", 1)
     # option lds_tlas: the tree's top levels (1) or the whole tree (2) staged into LDS -- same bits, same counters
     try:
-        for staged in (1, 2):
+        for staged in (1, 2) if experiments_build() else ():
             tracer.set_option("lds_tlas", staged)
             for counters in (True, False):
                 tracer.set_counters(counters)
@@ -868,6 +873,19 @@ def _wavefront_check(rt, oracle, tracer, arrays, w, h, bounces, spp, frames0=0, 
     return ref
 
 
+def test_experimental_options_are_rejected_by_the_product_library(rt, tracer):
+    """lds_top, lds_tlas, hybrid, wavefront: built, parity-tested, measured slower -- compiled only with
+    -DRT_EXPERIMENTS=1.  The product library refuses to switch them on (0 = off is accepted: it is what it does)."""
+    if experiments_build():
+        pytest.skip("this is the experiments build")
+    for name in ("lds_top", "lds_tlas", "hybrid", "wavefront"):
+        tracer.set_option(name, 0)
+        with pytest.raises(rt.RtError) as e:
+            tracer.set_option(name, 1)
+        assert e.value.code == -1 and "RT_EXPERIMENTS" in str(e.value)
+
+
+@pytest.mark.skipif("not experiments_build()", reason="the wavefront sequence needs the -DRT_EXPERIMENTS=1 build")
 def test_wavefront_sequences_do_not_change_the_bits(rt, oracle, tracer):
     """Option wavefront (RenderArgs::wf_*): path state in memory slots, rt_wf_shade_kernel and rt_wf_walk_kernel
     alternating -- on the many-mesh scenes (top-level trees, single meshes with root-box culling, root-leaf meshes,
