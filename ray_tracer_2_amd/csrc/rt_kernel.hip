@@ -255,7 +255,18 @@ DEV uint32_t fbits(float f) { return __float_as_uint(f); }
 // Built-and-measured-slower features (LDS-staged BVH / tree tops, hybrid launches, the wavefront sequence: DESIGN.md
 // sections 5.4, 5.5) are only compiled with -DRT_EXPERIMENTS=1 (tools/build_variant.sh exp -DRT_EXPERIMENTS=1); the
 // product library has none of their code.
-#if RT_EXPERIMENTS
+// The two record fetches of the global-memory kernels keep their "is this record staged in LDS?" test even in the product
+// build, where nothing is ever staged (RenderArgs::top_count = tlas_lds = 0: the test is wave-uniform and always false).
+// Measured, not argued: without the two tests hipcc 7.2 schedules the node-fetch loops differently and the kernels are
+// slower -- sponza-sized stand-in 5.67 -> 5.92 ms per frame, config 3 stand-in 5.26 -> 5.37 (either test alone: no gain;
+// profiles/r04_dead_branch_ab.txt, tools/experiments/README.md).  -DRT_TOP_BRANCH=0 -DRT_TLAS_BRANCH=0 compiles them out.
+#ifndef RT_TOP_BRANCH
+#define RT_TOP_BRANCH 1
+#endif
+#ifndef RT_TLAS_BRANCH
+#define RT_TLAS_BRANCH 1
+#endif
+#if RT_EXPERIMENTS || RT_TOP_BRANCH || RT_TLAS_BRANCH
 // float4 offset of the LDS-staged BVH top (global-memory kernels): behind the wave regions and cost tables
 DEV uint32_t top_lds_off16(const RenderArgs& a);
 DEV uint32_t tlas_lds_off16(const RenderArgs& a);
@@ -265,7 +276,7 @@ DEV uint32_t tlas_lds_off16(const RenderArgs& a);
 // LDS-staged top of the big mesh's BVH, option "lds_top").
 template <bool LDS>
 DEV void load_wide(const RenderArgs& a, uint32_t idx, float4& q0, float4& q1, float4& q2, float4& q3) {
-#if RT_EXPERIMENTS
+#if RT_TOP_BRANCH
     if constexpr (!LDS) {
         const uint32_t rel = idx - a.top_base;
         if (rel < a.top_count) {
@@ -283,7 +294,7 @@ DEV void load_wide(const RenderArgs& a, uint32_t idx, float4& q0, float4& q1, fl
 // the LDS-staged copy of the tree, option "lds_tlas").
 template <bool LDS>
 DEV void load_tlas(const RenderArgs& a, uint32_t e, float4& q0, float4& q1, float4& q2, float4& q3) {
-#if RT_EXPERIMENTS
+#if RT_TLAS_BRANCH
     if constexpr (!LDS) {
         if (e < a.tlas_lds) {  // (the first tlas_lds records -- the top levels, numbered breadth-first -- are staged)
             const float4* p = lds_mem + tlas_lds_off16(a) + e * 4u;
@@ -1296,7 +1307,7 @@ DEV uint32_t wave_region_dwords(const RenderArgs& a) {
            stack_dwords(a) + a.tlas_entries * 64u;
 }
 
-#if RT_EXPERIMENTS
+#if RT_EXPERIMENTS || RT_TOP_BRANCH || RT_TLAS_BRANCH
 DEV uint32_t top_lds_off16(const RenderArgs& a) { return (WAVES_PER_BLOCK * wave_region_dwords(a) + WAVES_PER_BLOCK * 8u * 3u) >> 2; }
 DEV uint32_t tlas_lds_off16(const RenderArgs& a) { return top_lds_off16(a) + a.top_count * 4u; }
 #endif
