@@ -362,8 +362,9 @@ void* rt_stream(rt_handle* h);
  * state x, 15 f32(u32 bits x) * 2^-32, 16 normalize(x, y, x*y).x, 17 the kernels' reciprocal rcp_(x), 18 their
  * sqrt_dev(x).  The second call filters one RGBA8 sRGB texture at n (u, v) pairs (wgsl:455 as csrc/rt_texture.h defines
  * it).  The third compares the kernels' short reciprocal (which = 0) / square root (which = 1) with the compiler's IEEE
- * 1.0f / x / sqrt on the device for EVERY float in the range the short form serves: out3 = {floats checked,
- * mismatches, a mismatching bit pattern}. */
+ * 1.0f / x / sqrt on the device for EVERY float in the range the short form serves, and the sky's three shortcuts
+ * (which = 2, 3, 4: wgsl:215-218 with the branches of smoothstep / pow taken apart) with their literal forms for every
+ * float in [-1.5, 1.5] / [0, 1.5]: out3 = {floats checked, mismatches, a mismatching bit pattern}. */
 int rt_test_device_units(rt_handle* h, int fn, const float* x, const float* y, float* out, uint64_t n);
 int rt_test_sweep(rt_handle* h, int which, uint64_t* out3);
 int rt_test_device_sample_texture(rt_handle* h, const rt_texture_desc* tex, const float* uv, float* rgba_out,

@@ -103,6 +103,7 @@ struct rt_handle {
     hipEvent_t pipe_book = nullptr;                    // the last tile-order / primary-table rebuild (recorded on a pipe stream)
     hipEvent_t pipe_main = nullptr;                    // the last launch that was not pipelined (recorded on the handle's stream)
     bool pipe_sampled_set[PIPE_MAX] = {}, pipe_blended_set[PIPE_MAX] = {}, pipe_book_set = false, pipe_main_set = false;
+    bool pipe_main_need = true;                        // pipelined frames have to wait for pipe_main before they sample (render_impl)
     float4* pipe_scratch[PIPE_MAX] = {};
     size_t pipe_scratch_texels = 0;
     uint32_t* pipe_work[PIPE_MAX] = {};                // a ring of launch counters per pipe stream
@@ -1463,13 +1464,15 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     const uint32_t pipe_depth = pipeline_opt >= 2 ? (uint32_t)pipeline_opt : 2u;
     bool pipe = pipeline_opt != 0 && n_batch == 0 && params->debug_flag == 0 && params->rays_per_pixel > 0 &&
                 !rounds && !wavefront_wanted;   // (strips too: the gather reads the image behind the blend, on the handle's stream)
+    bool took_idle_path = false;  // this frame would have been pipelined, found nothing in flight and takes the plain launch
+    bool wrote_tables = false;    // this launch rewrites a table later launches read (tile order, tile costs, primary table)
     if (pipe && h->pipeline_when_idle == 0) {
         // Every pipelined frame ends with its blend on the handle's stream: an idle stream means no frame is in flight,
         // i.e. this frame has nothing to overlap with (yet).  It takes the plain launch; the frames a host issues while
         // this one runs are pipelined behind it.
         const hipError_t q = hipStreamQuery(h->stream);
         (void)hipGetLastError();  // (hipErrorNotReady is an answer, not a failure: do not leave it for the launchers' hipGetLastError)
-        if (q == hipSuccess) pipe = false;
+        if (q == hipSuccess) { pipe = false; took_idle_path = true; }
         else if (q != hipErrorNotReady) return fail(h, RT_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
     }
     const uint32_t pslot = h->pipe_seq % pipe_depth;
@@ -1518,7 +1521,10 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             }
         }
         if (h->pipe_book_set) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_book, 0));
-        if (h->pipe_main_set) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_main, 0));
+        // (not for a frame that took the plain launch because nothing was in flight and rewrote no table: the host SAW the
+        // stream idle before it, so everything older is complete; this frame's samples go to a scratch image, and its blend
+        // follows that launch in the handle's stream's order anyway -- so the second frame of a burst overlaps the first)
+        if (h->pipe_main_set && h->pipe_main_need) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_main, 0));
         if (a.pixel_cache == 2u && pslot != 0u) {   // the global-memory memo is per resident wave: one per concurrent launch
             const size_t need = (size_t)h->persistent_blocks * WAVES_PER_BLOCK * PIXEL_MEMO_DWORDS * 64u;
             if (h->pipe_memo_words[pslot] < need) {
@@ -1531,8 +1537,13 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         }
     }
     auto barrier_other = [&]() -> hipError_t {   // before rewriting a shared table: the other stream's sampling launch is done
+        wrote_tables = true;
         if (!pipe || pipe_barrier) return hipSuccess;
         pipe_barrier = true;
+        if (h->pipe_main_set) {   // (... and whatever the handle's stream last launched outside the pipeline)
+            const hipError_t e = hipStreamWaitEvent(S, h->pipe_main, 0);
+            if (e != hipSuccess) return e;
+        }
         for (uint32_t k = 0; k < (uint32_t)rt_handle::PIPE_MAX; ++k)
             if (k != pslot && h->pipe_sampled_set[k]) {
                 const hipError_t e = hipStreamWaitEvent(S, h->pipe_sampled[k], 0);
@@ -1692,6 +1703,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         if (!h->have_order || h->order_age + frames_now >= (uint32_t)h->tile_feedback_period) {
             h->cost_slot ^= 1;
             a.tile_cost = h->tile_cost[h->cost_slot];
+            wrote_tables = true;
             HIP_TRY(h, hipMemsetAsync(a.tile_cost, 0, (size_t)n_tiles * sizeof(uint32_t), S));
             h->costs_ready = true;
         }
@@ -1897,6 +1909,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         if (h->pipe_stream[0]) {   // (pipelined frames may follow: their streams wait for this launch)
             HIP_TRY(h, hipEventRecord(h->pipe_main, h->stream));
             h->pipe_main_set = true;
+            h->pipe_main_need = !(took_idle_path && !wrote_tables);
         }
     }
     h->launches_total += 1;
@@ -2283,7 +2296,7 @@ int rt_test_device_units(rt_handle* h, int fn, const float* x, const float* y, f
 }
 
 int rt_test_sweep(rt_handle* h, int which, uint64_t* out3) {
-    if (!h || !out3 || which < 0 || which > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!h || !out3 || which < 0 || which > 4) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
     unsigned long long* d = nullptr;
     HIP_TRY(h, hipMalloc((void**)&d, 3 * sizeof(unsigned long long)));

@@ -1222,15 +1222,44 @@ DEV f4 sample_texture(const RenderArgs& a, int index, float u, float v) {
     return f4{out[0], out[1], out[2], out[3]};
 }
 
+// wgsl:214-221, literally (the definition; the render kernels call environment_light below)
+DEV float sky_gradient_t_literal(float y) { return rtm::pow_(smoothstep_(0.0f, 0.4f, y), 0.35f); }
+DEV float ground_to_sky_t_literal(float y) { return smoothstep_(-0.01f, 0.0f, y); }
+DEV float sun_literal(float m) { return rtm::pow_(m, 500.0f) * 0.1f; }  // m = max(0, dot(dir, (0.1, 1, 0.1)))
+
+// The same three values with the branches of their definitions taken apart -- same bits, ENUMERATED, not argued:
+// rt_sweep_kernel (which = 2, 3, 4) compares each with its literal form above for every float in [-1.5, 1.5] / [0, 1.5]
+// on the device (tests/test_gpu_device_units.py::test_sky_shortcuts_equal_the_literal_forms_for_every_float), and the
+// literal forms are what the oracle evaluates.
+//   smoothstep(lo, hi, y) clamps (y - lo) / (hi - lo) to [0, 1]: below lo it is 0, from hi on it is 1, and pow(0, 0.35) =
+//   exp2(0.35 * log2(0)) = exp2(-inf) = 0, pow(1, 0.35) = exp2(0) = 1 (rt_transc.h);
+//   pow(m, 500) = exp2(500 * log2(m)) and exp2_ returns +0 below -150: every m < 0.8 (log2 <= -0.32) gives +0.
+// An escaping ray mostly looks down or along the horizon: the two logarithm / exponential pairs and the two IEEE divisions
+// are then skipped for the whole wave (sky was 11 % of config 2's wave time, tools/diag.py --time).
+DEV float sky_gradient_t(float y) {
+    if (y <= 0.0f) return 0.0f;
+    if (y >= 0.4f) return 1.0f;
+    return sky_gradient_t_literal(y);  // (NaN comes here)
+}
+DEV float ground_to_sky_t(float y) {
+    if (y >= 0.0f) return 1.0f;
+    if (y <= -0.01f) return 0.0f;
+    return ground_to_sky_t_literal(y);
+}
+DEV float sun_term(float m) {
+    if (m < 0.8f) return 0.0f;
+    return sun_literal(m);
+}
+
 // wgsl:214-221
 DEV f4 environment_light(f3 dir) {
     const f4 SKY_HORIZON{1.0f, 1.0f, 1.0f, 0.0f};
     const f4 SKY_ZENITH{0.0788092f, 0.36480793f, 0.7264151f, 0.0f};
     const f4 GROUND{0.35f, 0.3f, 0.35f, 0.0f};
-    float sky_t = rtm::pow_(smoothstep_(0.0f, 0.4f, dir.y), 0.35f);
-    float g2s = smoothstep_(-0.01f, 0.0f, dir.y);
+    float sky_t = sky_gradient_t(dir.y);
+    float g2s = ground_to_sky_t(dir.y);
     f4 sky = mix4(SKY_HORIZON, SKY_ZENITH, sky_t);
-    float sun = rtm::pow_(max_(0.0f, dot3(dir, f3{0.1f, 1.0f, 0.1f})), 500.0f) * 0.1f;
+    float sun = sun_term(max_(0.0f, dot3(dir, f3{0.1f, 1.0f, 0.1f})));
     return mix4(GROUND, sky, g2s) + sun * (g2s >= 1.0f ? 1.0f : 0.0f);
 }
 
@@ -3138,17 +3167,28 @@ __global__ void __launch_bounds__(256) rt_units_texture_kernel(const uint8_t* rg
 }
 
 // Every float x the short forms serve: rcp_core(x) against the compiler's IEEE 1.0f / x (which = 0), sqrt_core(x)
-// against its sqrt (which = 1), bit for bit.  out[0] = floats checked, out[1] = mismatches, out[2] = a mismatching
-// bit pattern.
+// against its sqrt (which = 1), and the sky's shortcuts against their literal forms -- sky_gradient_t (2) and
+// ground_to_sky_t (3) for every float in [-1.5, 1.5] plus NaN and the infinities, sun_term (4) for every float in
+// [0, 1.5] (max(0, .) never hands it anything negative) -- bit for bit.  out[0] = floats checked, out[1] = mismatches,
+// out[2] = a mismatching bit pattern.
 __global__ void __launch_bounds__(256) rt_sweep_kernel(int which, unsigned long long* out) {
     unsigned long long checked = 0, bad = 0;
     for (unsigned long long b = (unsigned long long)blockIdx.x * 256u + threadIdx.x; b < (1ull << 32); b += (unsigned long long)gridDim.x * 256u) {
         const float x = __uint_as_float((uint32_t)b);
-        if (which == 0 ? !rcp_in_range(x) : !sqrt_in_range(x)) continue;
-        float q = which == 0 ? 1.0f / x : rtm::sqrt_(x);
+        bool in_range;
+        if (which == 0) in_range = rcp_in_range(x);
+        else if (which == 1) in_range = sqrt_in_range(x);
+        else if (which == 4) in_range = (x >= 0.0f && x <= 1.5f) || x != x;
+        else in_range = rtm::abs_(x) <= 1.5f || x != x || rtm::abs_(x) == __uint_as_float(0x7f800000u);
+        if (!in_range) continue;
+        float q = which == 0 ? 1.0f / x : which == 1 ? rtm::sqrt_(x) : which == 2 ? sky_gradient_t_literal(x)
+                                                     : which == 3 ? ground_to_sky_t_literal(x) : sun_literal(x);
         asm volatile("" : "+v"(q));
+        const float f = which == 0 ? rcp_core(x) : which == 1 ? sqrt_core(x) : which == 2 ? sky_gradient_t(x)
+                                                 : which == 3 ? ground_to_sky_t(x) : sun_term(x);
         checked += 1;
-        if (__float_as_uint(which == 0 ? rcp_core(x) : sqrt_core(x)) != __float_as_uint(q)) {
+        const bool both_nan = f != f && q != q;  // (NaN sign and payload are outside the arithmetic contract)
+        if (!both_nan && __float_as_uint(f) != __float_as_uint(q)) {
             bad += 1;
             out[2] = b;
         }

@@ -185,6 +185,18 @@ def test_rcp_is_the_ieee_division_for_every_float(tracer, oracle, rng):
         same_bits(tracer.device_units(FN["rcp"], v), oracle.transc("div", np.ones_like(v), v))
 
 
+@pytest.mark.parametrize("which,name,at_least", [(2, "sky_gradient_t", 2_100_000_000), (3, "ground_to_sky_t", 2_100_000_000),
+                                                   (4, "sun_term", 1_060_000_000)])
+def test_sky_shortcuts_equal_the_literal_forms_for_every_float(tracer, which, name, at_least):
+    """get_environment_light (wgsl:214-221) as the kernels evaluate it -- smoothstep's clamp and pow's two ends taken as
+    branches, so that a wave whose escaping rays look down skips both logarithm / exponential pairs and both divisions
+    -- against the literal formulas (which the oracle evaluates), on the device, for EVERY float the shader can hand them:
+    dir.y in [-1.5, 1.5] (a unit vector's component, generously), max(0, dot(dir, (0.1, 1, 0.1))) in [0, 1.5]."""
+    checked, bad, first = tracer.sweep(which)
+    assert checked >= at_least, (name, checked)
+    assert bad == 0, (name, bad, hex(first))
+
+
 def test_sqrt_dev_is_the_ieee_square_root_for_every_float(tracer, oracle, rng):
     """The same for the kernels' square root (v_sqrt_f32 + the neighbour test, without the scaling for denormals)."""
     checked, bad, first = tracer.sweep(1)
