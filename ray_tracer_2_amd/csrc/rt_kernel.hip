@@ -260,6 +260,11 @@ DEV uint32_t fbits(float f) { return __float_as_uint(f); }
 // Measured, not argued: without the two tests hipcc 7.2 schedules the node-fetch loops differently and the kernels are
 // slower -- sponza-sized stand-in 5.67 -> 5.92 ms per frame, config 3 stand-in 5.26 -> 5.37 (either test alone: no gain;
 // profiles/r04_dead_branch_ab.txt, tools/experiments/README.md).  -DRT_TOP_BRANCH=0 -DRT_TLAS_BRANCH=0 compiles them out.
+// The pre-step of path_step (a memoised primary segment is taken in the same iteration as the segment behind it): config 2
+// 1.1416 -> 1.1235 ms per frame, sponza-sized stand-in 5.679 -> 5.652, config 3 stand-in unchanged (tools/experiments/README.md).
+#ifndef RT_PRESTEP
+#define RT_PRESTEP 1
+#endif
 #ifndef RT_TOP_BRANCH
 #define RT_TOP_BRANCH 1
 #endif
@@ -1804,7 +1809,39 @@ DEV void park_load_hit(const RenderArgs& a, uint32_t slot, Isect& I, CompactHit&
 
 template <bool LDS, bool STATS, bool TLAS, bool PARK = false, bool SIMPLE = false, bool HYB = false>
 DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t& starve, uint32_t& n_segments,
-                       bool& reused, uint32_t& more_reused, int& node_tests, int& tri_tests, uint32_t resume_slot = 0xffffffffu) {
+                       bool& reused, bool& reused_pre, uint32_t& more_reused, int& node_tests, int& tri_tests, uint32_t resume_slot = 0xffffffffu) {
+#if RT_PRESTEP
+    // Pre-step: a lane at the start of a sample whose primary hit is memoised takes that segment NOW -- it needs no
+    // traversal -- and goes on to its next segment in the same iteration, so that it votes for (and joins) this
+    // iteration's traversal instead of shading here while the others wait and traversing one iteration later.  Pure
+    // scheduling: the lane's operations are path_begin's fresh branch, memo_hit_load and path_end, in that order, as before.
+    reused_pre = false;
+    if constexpr (!STATS) {
+        if ((!PARK || resume_slot == 0xffffffffu) && a.pixel_cache != 0u && s.fresh && a.params.number_of_bounces >= 0) {
+            uint32_t st = 0u;
+            f3 rd{0, 0, 0};
+            with_memo<false>(a, ls, [&](auto pc) {
+                st = pc[12 * 64];
+                rd = f3{__uint_as_float(pc[0]), __uint_as_float(pc[64]), __uint_as_float(pc[128])};
+            });
+            if ((st & (MEMO_RAY | MEMO_HIT_VALID)) == (MEMO_RAY | MEMO_HIT_VALID)) {
+                s.rd = rd;
+                s.rng = s.rng * 2200120369u + 878960812u;  // (the two disks' four draws: path_begin)
+                s.ro = f3{a.memo_ro[0], a.memo_ro[1], a.memo_ro[2]};
+                s.T = f4{1, 1, 1, 1};
+                s.light = f4{0, 0, 0, 0};
+                s.seg = 0;
+                s.fresh = false;
+                Hit mh;
+                mh.hit = false;
+                mh.suspended = false;
+                memo_hit_load<false>(a, ls, mh);
+                reused_pre = true;
+                if (path_end<LDS, total_in_lds(LDS), SIMPLE, true>(a, s, ls, STEP_REUSE, mh, n_segments, &more_reused)) return PATH_PIXEL_DONE;
+            }
+        }
+    }
+#endif
     // (a resumed pixel was parked behind path_begin: its segment has begun)
     const uint32_t mode = PARK && resume_slot != 0xffffffffu ? (uint32_t)STEP_RESUME : path_begin<STATS, SIMPLE, false, !LDS>(a, s, ls, starve);
     // segments served from the memo: the caller counts them per wave, OUTSIDE its `if (active)` (a ballot + a scalar
@@ -2023,10 +2060,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_tiles_k
     uint32_t n_segments = 0, n_reused_wave = 0, more_reused = 0;  // (more_reused: per lane, path_end's FAST_MISS)
     int node_tests = 0, tri_tests = 0;
     while (__ballot(active) != 0ull) {
-        bool reused = false;
-        if (active && path_step<LDS, STATS, TLAS, false, SIMPLE>(a, s, ls, starve, n_segments, reused, more_reused, node_tests, tri_tests) == PATH_PIXEL_DONE)
+        bool reused = false, reused_pre = false;
+        if (active && path_step<LDS, STATS, TLAS, false, SIMPLE>(a, s, ls, starve, n_segments, reused, reused_pre, more_reused, node_tests, tri_tests) == PATH_PIXEL_DONE)
             active = false;
-        n_reused_wave += (uint32_t)__popcll(__ballot(reused));  // (wave-uniform: every lane is here)
+        n_reused_wave += (uint32_t)__popcll(__ballot(reused)) + (uint32_t)__popcll(__ballot(reused_pre));  // (wave-uniform: every lane is here)
     }
     if (valid) pixel_finish<total_in_lds(LDS)>(a, s, ls);
     if (a.tile_cost && tile_ok) {  // one store per wave: the tile's rays
@@ -2157,9 +2194,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
         }
         TIC(t15);
         uint32_t step = PATH_CONTINUE;
-        bool reused = false;
+        bool reused = false, reused_pre = false;
         if (active) {
-            step = path_step<LDS, STATS, TLAS, PARK, SIMPLE, HYB>(a, s, ls, starve, n_segments, reused, more_reused, node_tests, tri_tests, resume_slot);
+            step = path_step<LDS, STATS, TLAS, PARK, SIMPLE, HYB>(a, s, ls, starve, n_segments, reused, reused_pre, more_reused, node_tests, tri_tests, resume_slot);
             resume_slot = 0xffffffffu;
             if (step == PATH_PIXEL_DONE) {
                 DIAG(16);
@@ -2169,7 +2206,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, RT_MIN_WAVES) rt_render_persist
             }
         }
         if (step == PATH_PARK) active = false;  // (parked by path_step)
-        n_reused_wave += (uint32_t)__popcll(__ballot(reused));  // (wave-uniform: every lane is here)
+        n_reused_wave += (uint32_t)__popcll(__ballot(reused)) + (uint32_t)__popcll(__ballot(reused_pre));  // (wave-uniform: every lane is here)
         TOC(t15, 15);
     }
     flush_counters<STATS>(a, n_segments, n_reused_wave, node_tests, tri_tests, more_reused);
