@@ -296,6 +296,9 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 fits (else global memory) / always in global memory
  *   primary_table         0 / 1 (1)               0: compute the memoised primary ray per pixel in the render kernel
  *                                                 instead of once per (camera, frame size)
+ *   primary_hits          0 / 1 (1)               the primary table also holds every pixel's primary HIT (once per camera, frame
+ *                                                 size, strip layout and scene): while the camera stands still no primary ray is
+ *                                                 traversed at all; 0: a pixel's first sample of every frame traverses it again
  *   vote_eighths          -1 / 0..8 (-1)          intersection vote: traverse when wanting lanes x 8 >= lanes x this
  *   vote_patience         -1 / >= 0 (-1)          ... or when some lane has waited this many iterations; -1: by the kind of
  *                                                 launch (6 and 3 for a scene in LDS on the few-mesh kernels, 7 and 16 for
@@ -324,11 +327,6 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *   tlas                  0 / 1 (1)  (upload)     top-level trees over the root boxes of many meshes in one local space
  *   tlas_min              >= 2 (8)   (upload)     smallest run of meshes that gets a top-level tree
  *   cull_roots            -1 / 0 / 1 (-1)         results-preserving root-box culling in the mesh loop (-1: from 16 meshes)
- *   lds_top               -1 / 0 / N (0)          wide BVH records of the biggest mesh staged into LDS when the scene is read
- *                                                 from global memory: what fits at full occupancy / none / N (<= 2048)
- *   lds_tlas              0 / 1 / 2 (0)           top-level tree records staged into LDS when the scene is read from global
- *                                                 memory: none / the top levels that fit at full occupancy / the whole tree
- *                                                 (measured slower both ways, DESIGN.md section 5.4)
  *   sort_rounds           -1 / 0 / 1..64 (-1)     deferred walks (one big mesh among a few): park pixels in front of the
  *                                                 mesh, walk it for all parked rays in a kernel of its own, resume --
  *                                                 for that many rounds; -1: by the work of the launch and the mesh's size,
@@ -338,14 +336,24 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 remaining samples are that segment again and their light is added in order
  *   park_levels           0 / 1 (1)               a parking launch runs the deferred walk's first two levels inline and parks
  *                                                 only the rays that reach a grandchild box (0: every ray that can hit the root box)
+ *   multi_rccl            0 / 1 / 2 (1)           gather of rt_render_multi: device-to-device copies / RCCL between
+ *                                                 distinct devices, copies otherwise (falls back to copies when librccl
+ *                                                 cannot be loaded) / RCCL or an error
+ *
+ * Only in a library built with -DRT_EXPERIMENTS=1 (tools/build_variant.sh exp -DRT_EXPERIMENTS=1; rt_version() then ends in
+ * "+experiments") -- features that were built, parity-tested and measured slower than what ships; the product library
+ * accepts 0 for them and rejects anything else with RT_ERR_INVALID_ARGUMENT:
+ *
+ *   lds_top               -1 / 0 / N (0)          wide BVH records of the biggest mesh staged into LDS when the scene is read
+ *                                                 from global memory: what fits at full occupancy / none / N (<= 2048)
+ *   lds_tlas              0 / 1 / 2 (0)           top-level tree records staged into LDS when the scene is read from global
+ *                                                 memory: none / the top levels that fit at full occupancy / the whole tree
+ *                                                 (measured slower both ways, DESIGN.md section 5.4)
  *   hybrid                0 / 1 (0)               the parking launches of a deferred-walk sequence stage everything but the big
  *                                                 mesh into LDS (measured no faster: DESIGN.md section 5.4)
  *   wavefront             0 / 1 (0)               wavefront sequences (many-mesh scenes): path state in memory slots, a shading
  *                                                 kernel and a ray-walk kernel with per-lane refill alternate (measured slower
  *                                                 than the inline kernels: DESIGN.md section 5.5)
- *   multi_rccl            0 / 1 / 2 (1)           gather of rt_render_multi: device-to-device copies / RCCL between
- *                                                 distinct devices, copies otherwise (falls back to copies when librccl
- *                                                 cannot be loaded) / RCCL or an error
  */
 int rt_set_option(rt_handle* h, const char* name, int value);
 /* Enable/disable the optional per-ray counters (node/triangle tests). */

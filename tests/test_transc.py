@@ -71,3 +71,50 @@ def test_special_values(oracle):
     assert oracle.transc("exp2", np.float32([-150, -149, 127]))[0] >= 0
     assert np.isnan(oracle.transc("acos", np.float32([1.5]))[0])
     assert np.isnan(oracle.transc("sqrt", np.float32([-1]))[0]) and np.isnan(oracle.transc("log", np.float32([nan]))[0])
+
+
+def test_normalize_stays_within_the_wgsl_bound(oracle):
+    """normalize(v) = v * (1 / sqrt(dot(v, v))) (one correctly rounded reciprocal of the correctly rounded
+    length, then a multiplication).  WGSL: normalize's accuracy is "inherited from e / length(e)", length's from
+    sqrt(dot(e, e)), and a division is good to 2.5 ULP -- so the bound is 2.5 ULP against e divided EXACTLY by the
+    binary32 length (the dot product in the shader's order, the correctly rounded square root).  Measured: 1.5.
+    Against the exact normalised vector the whole chain stays within 3 ULP."""
+    n = 400000
+    x = np.exp(RNG.uniform(-18, 18, n)).astype(np.float32) * RNG.choice([-1, 1], n).astype(np.float32)
+    y = np.exp(RNG.uniform(-18, 18, n)).astype(np.float32) * RNG.choice([-1, 1], n).astype(np.float32)
+    z = (x * y).astype(np.float32)
+    length32 = np.sqrt(((x * x).astype(np.float32) + (y * y).astype(np.float32)).astype(np.float32) + (z * z).astype(np.float32),
+                       dtype=np.float32)
+    ok = np.isfinite(length32) & (length32 > 1e-30)
+    got = oracle.transc("normalize_x", x, y)
+    assert ulp_err(got[ok], x[ok].astype(np.float64) / length32[ok].astype(np.float64)).max() <= 2.5
+    xd, yd, zd = (v.astype(np.float64) for v in (x, y, z))
+    assert ulp_err(got[ok], (xd / np.sqrt(xd * xd + yd * yd + zd * zd))[ok]).max() <= 3.0
+
+
+def test_log_on_every_rand_output(oracle):
+    """Box-Muller takes log(rand()) (wgsl:183) and rand() = f32(r) * 2^-32 takes every float of [2^-32, 1] (and 0): the
+    bound of test_log_on_rand_outputs on ALL 2.7e8 of them, not a sample (the polynomial was refitted in round 3)."""
+    worst = 0.0
+    for e in range(-32, 0):   # one binade at a time: 2^23 floats each
+        x = (np.arange(1 << 23, dtype=np.uint32) | np.uint32((e + 127) << 23)).view(np.float32)
+        worst = max(worst, float(ulp_err(oracle.transc("log", x), np.log(x.astype(np.float64))).max()))
+    assert worst <= 1.0, worst
+    assert oracle.transc("log", np.float32([1.0]))[0] == 0.0
+
+
+def test_sun_term_pow_500(oracle):
+    """get_environment_light's sun (wgsl:218): pow(max(0, dot(dir, (0.1, 1, 0.1))), 500).  (a) For every float in
+    [0.8, 1.02] -- the only inputs with a non-zero result: dot <= |dir| * |(0.1, 1, 0.1)| = 1.00995 -- the relative error
+    against double precision; (b) below 0.8 the result is exactly +0 (exp2_ returns +0 under -150: what the kernels'
+    early-out relies on; every float is compared on the device, here every 64th)."""
+    lo, hi = np.float32(0.8).view(np.uint32), np.float32(1.02).view(np.uint32)
+    x = np.arange(lo, hi + 1, dtype=np.uint32).view(np.float32)
+    got = oracle.transc("pow", x, np.full_like(x, 500.0)).astype(np.float64)
+    ref = np.power(x.astype(np.float64), 500.0)
+    ok = ref > 1e-35   # (below: denormal results)
+    rel = np.abs(got[ok] - ref[ok]) / ref[ok]
+    # y * log2(x) reaches 161 in magnitude: one ulp of log2 is worth 161 * 2^-24 * ln 2 in the result
+    assert rel.max() < 500 * 2.0 ** -23, rel.max()
+    below = np.arange(0, lo, 64, dtype=np.uint32).view(np.float32)
+    assert not oracle.transc("pow", below, np.full_like(below, 500.0)).view(np.uint32).any()
