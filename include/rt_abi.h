@@ -312,7 +312,7 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 0 / 2 / 3 / 4, config 3 stand-in 7.26 / 6.83 at 3 / 4).  Needs a hardware queue per
  *                                                 stream: -1 (and 1) = four frames when the host has set GPU_MAX_HW_QUEUES >= 5, three
  *                                                 otherwise; seven for a rank of a strip split of 4 ranks and more when there are
- *                                                 8 queues (the library never touches the environment)
+ *                                                 12 queues (the library never touches the environment)
  *   pipeline_when_idle    0 / 1 (0)               1 = also pipeline a frame that finds the handle's stream idle; by default such a
  *                                                 frame -- a host that renders, reads, renders: nothing to overlap with -- takes the
  *                                                 plain in-place launch (no scratch image, no blend kernel)

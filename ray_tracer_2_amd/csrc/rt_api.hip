@@ -228,12 +228,13 @@ namespace {
 // package and bench.py set it before they load anything): the automatic depth is four frames in flight when the host
 // has asked for five queues or more, three otherwise (1.29 against 1.23 ms per frame on four queues).  A rank of a
 // strip split whose share no longer fills the machine (world >= 4: 518 K pixels and fewer for 328 K resident lanes) runs
-// seven frames deep when there are eight queues: a frame's latency is then set by its longest pixel chain, not by its
+// seven frames deep when the host has asked for twelve queues or more -- room for the seven streams beside the host's own
+// (a framework's compute and copy streams, RCCL's): a frame's latency is then set by its longest pixel chain, not by its
 // work (rank 0's share of config 2 at world 8: 0.226 -> 0.207 ms per frame; profiles/r04_strip_pipeline_depth.txt).
 int automatic_pipeline_depth(uint32_t world) {
     const char* v = getenv("GPU_MAX_HW_QUEUES");
     const int queues = v ? atoi(v) : 4;
-    if (world >= 4 && queues >= 8) return 7;
+    if (world >= 4 && queues >= 12) return 7;
     return queues >= 5 ? 4 : 3;
 }
 

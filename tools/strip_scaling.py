@@ -20,10 +20,10 @@ tr.load_scene(arrays)
 base = {}
 # (mode, frames per launch, option pipeline): wall time per frame -- pipelined launches overlap, their event times do not add up
 for mode, batch, pipe in (("one launch per frame, no pipeline", 1, 0), ("one launch per frame, four frames in flight", 1, 4),
-                          ("one launch per frame, pipelined (default depth)", 1, -1), ("32 frames per launch", 32, -1)):
+                          ("one launch per frame, 4 frames (7 from world 4)", 1, -2), ("32 frames per launch", 32, -1)):
     tr.set_option("batch_frames", batch)
-    tr.set_option("pipeline", pipe)
     for world in (1, 2, 4, 8):
+        tr.set_option("pipeline", (7 if world >= 4 else 4) if pipe == -2 else pipe)
         ts = []
         for r in range(4):
             tr.synchronize()
