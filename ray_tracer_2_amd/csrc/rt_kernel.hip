@@ -265,6 +265,11 @@ DEV uint32_t fbits(float f) { return __float_as_uint(f); }
 #ifndef RT_PRESTEP
 #define RT_PRESTEP 1
 #endif
+// (not in the launches of a deferred-walk sequence: there its second copy of path_end costs 16 B more scratch per lane
+// than it saves -- config 3 stand-in 5.276 -> 5.260 ms per frame without it, config 5 geometry 3.152 -> 3.116)
+#ifndef RT_PRESTEP_PARK
+#define RT_PRESTEP_PARK 0
+#endif
 #ifndef RT_TOP_BRANCH
 #define RT_TOP_BRANCH 1
 #endif
@@ -1816,7 +1821,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
     // iteration's traversal instead of shading here while the others wait and traversing one iteration later.  Pure
     // scheduling: the lane's operations are path_begin's fresh branch, memo_hit_load and path_end, in that order, as before.
     reused_pre = false;
-    if constexpr (!STATS) {
+    if constexpr (!STATS && RT_PRESTEP_PARK >= (PARK ? 1 : 0)) {
         if ((!PARK || resume_slot == 0xffffffffu) && a.pixel_cache != 0u && s.fresh && a.params.number_of_bounces >= 0) {
             uint32_t st = 0u;
             f3 rd{0, 0, 0};
