@@ -704,6 +704,60 @@ def test_config4_sponza_standin(rt, oracle, tracer):
         assert same(gpu, ref), dbg
 
 
+def test_cross_mesh_pruning_and_foreign_hierarchies(rt, oracle, tracer):
+    """Cross-mesh pruning is only applied to items whose meshes passed the upload-time checks -- same
+    model_to_world as the mesh that gives the local ray, a BVH whose boxes really contain what is below them.  Foreign
+    arrays that break either must still render as the shader would (the oracle walks the SAME arrays, so a box that does
+    not contain its triangles misses them on both sides): a leaf box shrunk away from its triangle, a child box that sticks
+    out of its parent's, a model_to_world that differs from its run's by one bit, a model_to_world that is nothing like the
+    inverse -- pruned, unpruned and the counter kernels, against the oracle."""
+    from ray_tracer_2_amd import scenes
+    base = rt.SceneArrays.from_scene(scenes.sponza_standin(60, detail=3))
+    p = rt.make_params(160, 90, 4, 3, skybox=1, frames=0)
+
+    def variant(edit):
+        meshes, nodes = base.meshes.copy(), base.nodes.copy()
+        edit(meshes, nodes)
+        return rt.SceneArrays(base.uniform, base.spheres, meshes, base.triangles, nodes, base.textures)
+
+    def leaf_of(nodes, mesh):   # a leaf node of mesh `mesh`
+        k = int(base.meshes["node_offset"][mesh])
+        while nodes["count"][k] == 0:
+            k = int(base.meshes["node_offset"][mesh]) + int(nodes["left"][k])
+        return k
+
+    def shrink_leaf(meshes, nodes):
+        k = leaf_of(nodes, 7)
+        nodes["aabb_max"][k] = nodes["aabb_min"][k] + (nodes["aabb_max"][k] - nodes["aabb_min"][k]) * np.float32(0.25)
+
+    def child_sticks_out(meshes, nodes):
+        k = int(base.meshes["node_offset"][9]) + int(nodes["left"][int(base.meshes["node_offset"][9])])
+        nodes["aabb_max"][k] += np.float32(3.0)
+
+    def one_bit(meshes, nodes):
+        m = meshes["model_to_world"][11].view(np.uint32)
+        m[0, 0] ^= np.uint32(1)
+
+    def not_an_inverse(meshes, nodes):
+        for i in range(12, 30):   # (a whole stretch of the run: the tree loses its permission to prune)
+            meshes["model_to_world"][i][3][:3] += np.float32(0.37)
+
+    for name, edit in (("untouched", lambda m, n: None), ("shrunk leaf box", shrink_leaf), ("child box outside its parent", child_sticks_out),
+                       ("model_to_world off by one bit", one_bit), ("model_to_world not an inverse", not_an_inverse)):
+        a = variant(edit)
+        outs = {}
+        for prune, counters in ((1, False), (0, False), (1, True)):
+            tracer.set_option("cross_prune", prune)
+            tracer.set_counters(counters)
+            gpu, ref, s, st = render_both(rt, oracle, tracer, a, p)
+            assert same(gpu, ref), (name, prune, counters)
+            assert s.segments == st.segments
+            if counters:
+                assert (s.node_tests, s.triangle_tests) == (st.node_tests, st.triangle_tests), name
+        tracer.set_counters(False)
+        tracer.set_option("cross_prune", 1)
+
+
 def test_config4_sponza_sized_standin(rt, oracle, tracer):
     """The config 4 stand-in at sponza.obj's size (340 meshes of 768 triangles: 261 k triangles, the scene is
     read from global memory under the top-level tree) -- image and counters bit for bit, both kernel variants,
