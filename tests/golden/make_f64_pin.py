@@ -41,6 +41,57 @@ def oracle_sample(arrays, frame, bounces=BOUNCES, spp=1):
     return img
 
 
+def library_scenes(frames=48, w=160, h=90, spp=2, bounces=5):
+    """The scene library's procedural scenes (src/scene/scene.rs: room :445-573, metal :758-863, balls) -- spheres (ray_sphere
+    wgsl:223-256), glass (refract, Beer-Lambert, the short-circuit Fresnel draw: wgsl:414-436), mirrors, depth of field -- and
+    the texture filter (wgsl:455) on the reference's earthmap.png: the same statistics at a smaller size.  (texture_test's
+    FRAMES are not compared: its camera sits exactly on the unit sphere's surface (scene.rs: cam (0, 0, -1), radius 1), so
+    whether a ray starts inside or outside is decided by the last bit of |o - c|^2 - r^2 -- in any arithmetic.)"""
+    res = {}
+    data = os.path.join(ROOT, "tests", "data")
+    for name in ("room", "metal", "balls"):
+        arrays = rt.SceneArrays.from_scene(rt.Scene.from_name(name, data))
+        sc = I.Scene(arrays)
+        r = {"width": w, "height": h, "frames": frames, "spp": spp, "bounces": bounces}
+        views = {}
+        for mode, scale in ((1, 8), (2, 8), (3, 8), (4, 100)):
+            p = rt.make_params(w, h, 1, 1, skybox=1, frames=0)
+            p.debug_flag, p.debug_scale = mode, scale
+            ref, _ = oracle.render(p, arrays)
+            got, _hit = I.debug_view(sc, w, h, mode, scale)
+            views[f"view{mode}"] = {"max_abs_diff": float(np.abs(got - ref).max()), "hit_mask_mismatches": int(((got[..., 3] != 0) != (ref[..., 3] != 0)).sum())}
+        r["debug_views"] = views
+        s64 = np.zeros((h, w, 4)); q64 = np.zeros((h, w, 4)); s32 = np.zeros((h, w, 4)); s32o = np.zeros((h, w, 4))
+        same = []
+        for f in range(frames):
+            g = I.render_frame(sc, w, h, bounces, spp, f)
+            s64 += g
+            q64 += g * g
+            a, _ = oracle.render(rt.make_params(w, h, bounces, spp, skybox=1, frames=-f), arrays)
+            s32 += a
+            same.append(agree(g, a))
+            b, _ = oracle.render(rt.make_params(w, h, bounces, spp, skybox=1, frames=-(frames + f)), arrays)
+            s32o += b
+        m64 = s64 / frames
+        var = np.maximum(q64 / frames - m64 * m64, 0.0)
+        se = np.sqrt(var.mean((0, 1)) / (w * h * frames))
+        r["channel_mean_f64"] = m64.mean((0, 1)).tolist()
+        r["standard_error_of_channel_mean"] = se.tolist()
+        r["diff_same_seeds_in_standard_errors"] = (np.abs((s64 - s32).mean((0, 1)) / frames) / np.maximum(se, 1e-300)).tolist()
+        r["diff_disjoint_seeds_in_standard_errors_of_the_difference"] = (np.abs((s64 - s32o).mean((0, 1)) / frames) / np.maximum(np.sqrt(2.0) * se, 1e-300)).tolist()
+        r["per_frame_pixels_within_1e-5_same_seeds"] = {"min": min(same), "mean": float(np.mean(same))}
+        res[name] = r
+        print(name, json.dumps({k: r[k] for k in r if k != "debug_views"}), flush=True)
+    # the texture filter on the reference's own texture (earthmap.png through the loader: fixture)
+    tex = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "texture_test_scene.npz")).textures[0]
+    rng = np.random.default_rng(5)
+    uv = rng.uniform(-2.0, 3.0, (200000, 2)).astype(np.float32)
+    got = I.sample_texture(np.asarray(tex), uv[:, 0].astype(np.float64), uv[:, 1].astype(np.float64))
+    ref = oracle.sample_texture(tex, uv)
+    res["texture_filter_earthmap"] = {"samples": int(uv.shape[0]), "max_abs_diff": float(np.abs(got - ref).max())}
+    return res
+
+
 def main():
     F = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
@@ -111,6 +162,7 @@ def main():
         "disjoint_seeds_deterministic_channels_max_rel_diff": float(det_rel[~noisy].max()) if (~noisy).any() else 0.0,
         "progressive_accumulation_f32_vs_f64_mean_of_its_samples_max_rel": float((np.abs(acc - m32) / np.maximum(np.abs(m32), 1e-3)).max()),
     }
+    out["library_scenes"] = library_scenes()
     path = os.path.join(ROOT, "tests", "golden", "f64_pin.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out["converged"], indent=1))
