@@ -1554,6 +1554,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     };
     // Primary-ray table for the memo: recomputed when the camera or the frame size changed
     a.primary = nullptr;
+    a.primary_complete = 0u;
     if (h->use_primary && a.pixel_cache != 0 && params->debug_flag == 0 && params->rays_per_pixel > 0) {
         const size_t texels = (size_t)((params->width + 7) / 8) * ((params->height + 7) / 8) * 64;  // whole 8x8 tiles
         if (h->primary_texels < texels) {
@@ -1582,6 +1583,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             h->primary_camera = h->camera;
         }
         a.primary = h->primary;
+        a.primary_complete = h->primary_with_hits ? 1u : 0u;
     }
     // a fresh tile counter per launch: a ring of 64, zeroed in one go each time it wraps (launches on
     // one stream are ordered, so every earlier user of the ring is done by then)

@@ -181,6 +181,9 @@ struct RenderArgs {
     uint32_t* pixel_cache_mem;
     const void* primary;     // primary table of the frame (rt_primary_kernel: one 64-byte memo entry per pixel -- the constant
                              // primary ray and, with option "primary_hits", its hit), or null: compute per pixel
+    uint32_t primary_complete;  // != 0: the table holds the hits too, so a lane's memo EQUALS its table entry for the whole pixel
+                             // (memo_hit_store rewrites the same bits): park records leave the memo out and a resumed pixel
+                             // reloads it from the table
     float spp_reciprocal;     // 1 / rays_per_pixel when that is a power of two (exact), else 0
     float blend_weight, blend_rest;  // 1 / f32(frames + 1) and 1 - that (wgsl:157-158)
     float memo_ro[3];        // (origin + right * 0) + up * 0: the memoised primary rays' common origin
@@ -266,9 +269,10 @@ constexpr uint32_t WF_STATE_PLANES = 6, WF_HIT_PLANES = 2;
 // Park record of a pixel: 14 x 16 B, stored in blocks of 64 records, plane by plane (plane p of record i of block b at
 // float4 index (b * PARK_PLANES + p) * 64 + i), so that the lanes of a wave, which hold consecutive records, store and
 // load contiguous kilobytes.  Planes: 0 (x, out_row, rng, j)  1 (seg, fresh, meta, memo[12])  2 (ro, rd.x)
-// 3 (rd.yz, T.xy)  4 (T.zw, light.xy)  5 (light.zw, -, -)  6 total  7-9 memo[0..11]  10 (closest, object, any |
-// inside << 1, sphere dst)  11 (win_u, win_v, win_tri, win_point.x)  12 (win_point.yz, -, -)  13 the walk's result
-// (t, u, v, tri | det sign; tri = ~0: no hit), written by rt_walk_kernel.
+// 3 (rd.yz, T.xy)  4 (T.zw, light.xy)  5 (light.zw, win_point.yz)  6 total  7-9 memo[0..11] (left untouched when the
+// primary table holds the whole memo: RenderArgs::primary_complete)  10 (closest, object, any | inside << 1, sphere
+// dst)  11 (win_u, win_v, win_tri, win_point.x)  12 unused  13 the walk's result (t, u, v, tri | det sign; tri = ~0:
+// no hit), written by rt_walk_kernel.  A park writes 9 planes (144 B) and a resume reads 11 (176 B) in the usual case.
 constexpr uint32_t PARK_PLANES = 14;
 
 constexpr uint32_t RT_MAX_BATCH_FRAMES = 32;

@@ -1534,6 +1534,21 @@ DEV f3 memo_ray_of(const A& ca, const CameraConsts& c, uint32_t x, uint32_t y, b
     return rd;
 }
 
+// A pixel's memo from the primary table (see pixel_cache_begin)
+template <bool WF = false, class A>
+DEV void memo_from_table(const RenderArgs& a, const A& ca, const PixelState& s, uint32_t y, uint32_t* ls) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // (a plain vector: global_load_dwordx4 through the typed pointer)
+    const __attribute__((address_space(1))) u32x4* v =
+        (const __attribute__((address_space(1))) u32x4*)a.primary + primary_index(ca.params.width, s.x, y) * 4u;
+    const u32x4 e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+    with_memo<WF>(a, ls, [&](auto pc) {
+        pc[0] = e0.x; pc[64] = e0.y; pc[2 * 64] = e0.z; pc[3 * 64] = e0.w;
+        pc[4 * 64] = e1.x; pc[5 * 64] = e1.y; pc[6 * 64] = e1.z; pc[7 * 64] = e1.w;
+        pc[8 * 64] = e2.x; pc[9 * 64] = e2.y; pc[10 * 64] = e2.z; pc[11 * 64] = e2.w;
+        pc[12 * 64] = e3.x;
+    });
+}
+
 template <bool WF = false, bool SQ = false, class A>
 DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts& c, const PixelState& s, uint32_t* ls) {
     if (!a.pixel_cache) return;
@@ -1547,16 +1562,7 @@ DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts&
         // frame of the accumulation.  One 64-byte entry per pixel (the memo's 13 dwords, see path_begin), in the order in
         // which lanes take pixels (8x8 tile by tile, row-major inside): the lanes refilled together read neighbouring
         // entries.  Same inputs, same operations, same bits as the per-sample path.
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // (a plain vector: global_load_dwordx4 through the typed pointer)
-        const __attribute__((address_space(1))) u32x4* v =
-            (const __attribute__((address_space(1))) u32x4*)a.primary + primary_index(ca.params.width, s.x, y) * 4u;
-        const u32x4 e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
-        with_memo<WF>(a, ls, [&](auto pc) {
-            pc[0] = e0.x; pc[64] = e0.y; pc[2 * 64] = e0.z; pc[3 * 64] = e0.w;
-            pc[4 * 64] = e1.x; pc[5 * 64] = e1.y; pc[6 * 64] = e1.z; pc[7 * 64] = e1.w;
-            pc[8 * 64] = e2.x; pc[9 * 64] = e2.y; pc[10 * 64] = e2.z; pc[11 * 64] = e2.w;
-            pc[12 * 64] = e3.x;
-        });
+        memo_from_table<WF>(a, ca, s, y, ls);
         return;
     }
     rd = memo_ray_of<SQ>(ca, c, s.x, y, constant_ray);
@@ -1920,7 +1926,8 @@ DEV void park_store(const RenderArgs& a, uint32_t slot, const PixelState& s, uin
     // (the memo's 13 dwords as named values: an indexed local array kept its 52 bytes of scratch frame)
     float4 m0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), m1 = m0, m2 = m0;
     uint32_t m12 = 0u;
-    if (a.pixel_cache != 0u)
+    const bool memo_kept = a.pixel_cache != 0u && a.primary_complete == 0u;  // (else the table holds it: RenderArgs::primary_complete)
+    if (memo_kept)
         with_memo(a, ls, [&](auto pc) {
             m0 = make_float4(u(pc[0 * 64]), u(pc[1 * 64]), u(pc[2 * 64]), u(pc[3 * 64]));
             m1 = make_float4(u(pc[4 * 64]), u(pc[5 * 64]), u(pc[6 * 64]), u(pc[7 * 64]));
@@ -1932,19 +1939,20 @@ DEV void park_store(const RenderArgs& a, uint32_t slot, const PixelState& s, uin
     q[2 * 64] = make_float4(s.ro.x, s.ro.y, s.ro.z, s.rd.x);
     q[3 * 64] = make_float4(s.rd.y, s.rd.z, s.T.x, s.T.y);
     q[4 * 64] = make_float4(s.T.z, s.T.w, s.light.x, s.light.y);
-    q[5 * 64] = make_float4(s.light.z, s.light.w, 0.0f, 0.0f);
+    q[5 * 64] = make_float4(s.light.z, s.light.w, I.win_point.y, I.win_point.z);
     q[6 * 64] = make_float4(total.x, total.y, total.z, total.w);
-    q[7 * 64] = m0;
-    q[8 * 64] = m1;
-    q[9 * 64] = m2;
+    if (memo_kept) {
+        q[7 * 64] = m0;
+        q[8 * 64] = m1;
+        q[9 * 64] = m2;
+    }
     q[10 * 64] = make_float4(I.closest, u((uint32_t)I.object), u((I.any ? 1u : 0u) | (I.s_inside ? 2u : 0u)), I.s_dst);
     q[11 * 64] = make_float4(I.win_u, I.win_v, u(I.win_tri), I.win_point.x);
-    q[12 * 64] = make_float4(I.win_point.y, I.win_point.z, 0.0f, 0.0f);
 }
 // the closest-hit record of the parked segment and the walk's result
 DEV void park_load_hit(const RenderArgs& a, uint32_t slot, Isect& I, CompactHit& walked) {
     const float4* q = a.q_in + (size_t)(slot >> 6) * (PARK_PLANES * 64u) + (slot & 63u);
-    const float4 p10 = q[10 * 64], p11 = q[11 * 64], p12 = q[12 * 64], p13 = q[13 * 64];
+    const float4 p10 = q[10 * 64], p11 = q[11 * 64], p5 = q[5 * 64], p13 = q[13 * 64];
     I.closest = p10.x;
     I.object = (int)fbits(p10.y);
     I.any = (fbits(p10.z) & 1u) != 0u;
@@ -1953,7 +1961,7 @@ DEV void park_load_hit(const RenderArgs& a, uint32_t slot, Isect& I, CompactHit&
     I.win_u = p11.x;
     I.win_v = p11.y;
     I.win_tri = fbits(p11.z);
-    I.win_point = f3{p11.w, p12.x, p12.y};
+    I.win_point = f3{p11.w, p5.z, p5.w};
     walked = CompactHit{p13.x, p13.y, p13.z, fbits(p13.w)};
 }
 template <bool TOTAL_LDS>
@@ -1970,7 +1978,10 @@ DEV void park_load(const RenderArgs& a, uint32_t slot, PixelState& s, uint32_t* 
     if constexpr (TOTAL_LDS) {
         ls[0] = fbits(p6.x); ls[64] = fbits(p6.y); ls[128] = fbits(p6.z); ls[192] = fbits(p6.w);
     }
-    if (a.pixel_cache != 0u) {
+    if (a.pixel_cache != 0u && a.primary_complete != 0u) {
+        const ColdArgs& ca = cold_args();
+        memo_from_table(a, ca, s, frame_row_of(ca, s.out_row), ls);
+    } else if (a.pixel_cache != 0u) {
         const float4 p7 = q[7 * 64], p8 = q[8 * 64], p9 = q[9 * 64];
         with_memo(a, ls, [&](auto pc) {
             pc[0 * 64] = fbits(p7.x); pc[1 * 64] = fbits(p7.y); pc[2 * 64] = fbits(p7.z); pc[3 * 64] = fbits(p7.w);
