@@ -277,6 +277,7 @@ def main():
         # (outside the timed region) one launch per frame WITHOUT the pipeline (option pipeline = 0: every launch ramps up and
         # drains alone, in-place blend) -- the latency of a frame, and what round 2 called the un-overlapped frame
         tracer.set_option("pipeline", 0)
+        tracer.set_option("frame_ahead", 0)   # (every frame a launch of its own)
         seq = []
         for rep in range(3):
             tracer.synchronize()
@@ -288,16 +289,22 @@ def main():
             seq.append((time.perf_counter() - t1) / 64 * 1e3)
         s1 = tracer.stats()
         tracer.set_option("pipeline", 1)   # (back to the default depth)
+        tracer.set_option("frame_ahead", -1)
         extras["ms_per_frame_unoverlapped"] = statistics.median(seq)
         extras["kernel_ms_unoverlapped"] = s1.kernel_ms / max(s1.launches, 1)
         # The reference's present loop (src/core/app.rs:285-340): render one frame, consume it, render the next -- here
         # "consume" = wait for the frame (rt_synchronize; a host copy of the 33 MB frame over PCIe would add ~0.6 ms to
         # every variant alike).  Nothing overlaps in such a loop, so by default a frame that finds the stream idle takes
         # the plain in-place launch (option pipeline_when_idle = 0); with 1 it pays the pipeline's scratch image, blend
-        # kernel and event hops for nothing.
+        # kernel and event hops for nothing.  By default (option frame_ahead = -1) a call that continues an accumulation
+        # and finds the stream idle renders the next frames with its own (batches of 2, then 3 at this size): the calls
+        # that follow only blend theirs -- the average over the 32 frames is what is reported, the image after every call
+        # is the same.
         import numpy as np
         present = {}
-        for name, opts in (("default", {}), ("pipeline_when_idle", {"pipeline_when_idle": 1}), ("pipeline_off", {"pipeline": 0})):
+        for name, opts in (("default", {}), ("frame_ahead_off", {"frame_ahead": 0}),
+                           ("frame_ahead_off_pipeline_when_idle", {"frame_ahead": 0, "pipeline_when_idle": 1}),
+                           ("frame_ahead_off_pipeline_off", {"frame_ahead": 0, "pipeline": 0})):
             for k, v in opts.items():
                 tracer.set_option(k, v)
             ts = []
@@ -311,6 +318,7 @@ def main():
             present[name] = statistics.median(ts)
             tracer.set_option("pipeline", 1)
             tracer.set_option("pipeline_when_idle", 0)
+            tracer.set_option("frame_ahead", -1)
         extras["ms_per_frame_render_then_wait"] = present
         # first frame after a camera change at full size: natural tile order, primary-ray table rebuilt
         cam_t = type(arrays.uniform.camera)
@@ -413,7 +421,9 @@ def main():
                                 "(intermediate frames of a batch are not observable); value_per_frame_launch = the same frames "
                                 "with one launch" + (" and one gather" if world > 1 else "") + " per frame, every frame observable, timed "
                                 "right after (N = 1: consecutive launches pipelined across internal streams, four frames in flight, option pipeline; "
-                                "ms_per_frame_unoverlapped = the same with the pipeline off = a frame's latency)",
+                                "ms_per_frame_unoverlapped = the same with the pipeline off = a frame's latency; N >= 2: a call that continues "
+                                "the accumulation renders the next frames of the rank's small share with its own and the following calls blend "
+                                "theirs, option frame_ahead -- every call still leaves its frame in the image, and the gather is per frame)",
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "CornellBox-Original.obj/.mtl of the reference through the loader + BVH builder "
                     "(committed as tests/golden/cornell_scene.npz); no random inputs: the seed is Params.frames",

@@ -316,6 +316,15 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *   pipeline_when_idle    0 / 1 (0)               1 = also pipeline a frame that finds the handle's stream idle; by default such a
  *                                                 frame -- a host that renders, reads, renders: nothing to overlap with -- takes the
  *                                                 plain in-place launch (no scratch image, no blend kernel)
+ *   frame_ahead           -1 / 0 / 2..32 (-1)     one-frame calls (rt_render, rt_render_strips, rt_render_multi) that continue an
+ *                                                 accumulation (same parameters, camera, scene and options, frames = f, f + 1, ...):
+ *                                                 the call for frame f renders frames f .. f + d - 1 in one batched launch and blends
+ *                                                 frame f; the next d - 1 calls only blend theirs (the image after every call is
+ *                                                 bit-identical; a call that does not continue the sequence drops the rest).  -1 =
+ *                                                 automatic: only for an LDS-resident scene and a share too small for a launch of its
+ *                                                 own to keep the lanes full (batches of about 4 ms: 28 / 14 / 7 frames for a strip
+ *                                                 share of 8 / 4 / 2 ranks of config 2, none for the whole frame); 0 = off.  The
+ *                                                 counters of rt_get_stats count a batch when it is launched
  *   cross_prune           0 / 1 (1)               many-mesh kernels: boxes and meshes whose entry distance lies beyond a bound derived
  *                                                 from the closest hit so far (error budget + 12.5 % slack) are not
  *                                                 entered; never in the counter / debug kernels
@@ -379,7 +388,8 @@ int rt_test_device_sample_texture(rt_handle* h, const rt_texture_desc* tex, cons
                                   uint64_t n);
 
 /* Test-only: raw copy of a buffer of the last wavefront sequence (which: 0 path state, 1 hit records, 2 the two slot
- * lists, 3 the per-round list counts; layouts in csrc/rt_device.h). */
+ * lists, 3 the per-round list counts; layouts in csrc/rt_device.h), or (which = 4) the pixels parked in front of each round
+ * of the last deferred-walk sequence (72 u32). */
 int rt_test_read_wavefront(rt_handle* h, int which, void* out, uint64_t bytes);
 /* The grouped ncclSend / ncclRecv gather of rt_render_multi against the RCCL-shaped library at `lib_path`, on fake
  * buffers and without any HIP call (runs without a GPU): checks that a failure inside the group still closes the group

@@ -96,6 +96,32 @@ struct rt_handle {
     // only then renders again, the reference's present loop -- has nothing to overlap with and takes the plain in-place
     // launch (no scratch image, no blend kernel, no event hops); 1 = pipeline such frames too
     int pipeline_when_idle = 0;
+    // Frames rendered ahead (option "frame_ahead"): a host that accumulates calls rt_render with the same parameters and
+    // frames = f, f + 1, f + 2, ...  When a share is so small that one launch per frame cannot keep the lanes full (a strip
+    // share of four or eight ranks, a small window), the call for frame f renders frames f .. f + d - 1 in ONE batched launch
+    // (the persistent kernel refills its lanes across frames) into the batch scratch images and blends frame f only; the
+    // calls for f + 1 .. f + d - 1 find their frame rendered and only blend it -- same bits, same image after every call.
+    // A call that does not continue the sequence (other parameters, camera, scene, option, strip layout) drops what is left.
+    int frame_ahead = -1;                              // -1 automatic (ahead_depth()), 0 off, 2 .. 32 frames
+    bool frame_ahead_failed = false;                   // the batch could not be set up once (memory): automatic stays off
+    uint32_t ahead_ramp = 2;                           // automatic: batches of 2, 4, 8, ... frames up to ahead_depth() while the
+                                                       // sequence goes on, so that a host that stops after n frames has had
+                                                       // at most n rendered in vain; back to 2 when the sequence breaks
+    uint64_t generation = 0;                           // bumped by everything that changes what a frame looks like
+    struct {
+        bool valid = false;
+        rt_params base{};                              // the parameters of slot 0
+        uint32_t n = 0, next = 0;                      // slots rendered / the next one to hand out
+        uint32_t rank = 0, world = 1;
+        uint64_t generation = 0;
+        uint64_t texels = 0;                           // slot stride
+    } ahead;
+    struct {
+        bool valid = false;
+        rt_params params{};
+        uint32_t rank = 0, world = 1;
+        uint64_t generation = 0;
+    } last_single;                                     // the last one-frame call (render_single)
     uint32_t pipe_layout[PIPE_MAX][5] = {};            // (w, h, rank, world, texels) each scratch image's padding rows were zeroed for
     hipStream_t pipe_stream[PIPE_MAX] = {};
     hipEvent_t pipe_sampled[PIPE_MAX] = {};            // frame sampled into scratch[i] (recorded on pipe_stream[i])
@@ -460,6 +486,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
                     const rt_packed_triangle* triangles, uint32_t n_triangles, const rt_node* nodes,
                     uint32_t n_nodes) {
     if (!h || !scene) return fail(h, RT_ERR_INVALID_ARGUMENT, "null handle or scene");
+    h->generation += 1;
     if ((n_spheres && !spheres) || (n_meshes && !meshes) || (n_triangles && !triangles) || (n_nodes && !nodes))
         return fail(h, RT_ERR_INVALID_ARGUMENT, "null array with non-zero count");
     // ray_tracer.rs:15-19, bvh.rs:140
@@ -1121,6 +1148,7 @@ static int wait_pending_copy(rt_handle* h) {
 
 int rt_upload_textures(rt_handle* h, const rt_texture_desc* descs, uint32_t n) {
     if (!h || (n && !descs)) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    h->generation += 1;
     if (n > RT_MAX_TEXTURES) return fail(h, RT_ERR_CAPACITY, "Cannot load more than 64 textures");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1146,6 +1174,8 @@ int rt_upload_textures(rt_handle* h, const rt_texture_desc* descs, uint32_t n) {
 
 int rt_set_camera(rt_handle* h, const rt_camera_uniform* camera) {
     if (!h || !camera) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    // (a host that re-sends the same camera every frame -- the reference's update_buffers -- keeps its frames rendered ahead)
+    if (memcmp(&h->camera, camera, sizeof(rt_camera_uniform)) != 0) h->generation += 1;
     h->camera = *camera;
     return RT_OK;
 }
@@ -1153,6 +1183,7 @@ int rt_set_camera(rt_handle* h, const rt_camera_uniform* camera) {
 int rt_set_option(rt_handle* h, const char* name, int value) {
     if (!h || !name) return RT_ERR_INVALID_ARGUMENT;
     std::string n(name);
+    h->generation += 1;  // (frames rendered ahead under the old setting are dropped: render_single)
     if (n == "kernel_variant") {
         if (value < -1 || value > 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "kernel_variant must be -1 (auto), 0 or 1");
         h->kernel_variant = value;
@@ -1220,6 +1251,11 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         h->pipeline = value == 1 ? -1 : value;
     } else if (n == "pipeline_when_idle") {
         h->pipeline_when_idle = value ? 1 : 0;
+    } else if (n == "frame_ahead") {
+        if (value < -1 || value == 1 || value > (int)RT_MAX_BATCH_FRAMES)
+            return fail(h, RT_ERR_INVALID_ARGUMENT, "frame_ahead must be -1 (automatic), 0 (off) or 2 .. 32 (frames per batch)");
+        h->frame_ahead = value;
+        h->frame_ahead_failed = false;
     } else if (n == "fast_miss") {
         h->fast_miss = value ? 1 : 0;
     } else if (n == "park_levels") {
@@ -1248,6 +1284,7 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
 int rt_set_counters(rt_handle* h, int enabled) {
     if (!h) return RT_ERR_INVALID_ARGUMENT;
     h->count_tests = enabled ? 1 : 0;
+    h->generation += 1;
     return RT_OK;
 }
 
@@ -1278,8 +1315,10 @@ static hipError_t harvest_event_times(rt_handle* h, double& sum_ms) {
     return hipSuccess;
 }
 
-static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world, uint32_t n_batch = 0) {
+static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world, uint32_t n_batch = 0,
+                       bool blend_later = false) {
     if (!h || !params) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    h->ahead.valid = false;  // (whatever launches here breaks a sequence of frames rendered ahead: render_single)
     if (!h->have_scene) return fail(h, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
     if (world == 0 || rank >= world) return fail(h, RT_ERR_INVALID_ARGUMENT, "bad rank/world");
     if (params->width == 0 || params->height == 0) return fail(h, RT_ERR_INVALID_ARGUMENT, "empty image");
@@ -1891,7 +1930,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             HIP_TRY(h, launch_render(last ? a : ah, h->stream));
         }
     }
-    if (n_batch) {
+    if (n_batch && !blend_later) {
         BlendArgs b{};
         b.image = h->image;
         b.scratch = h->batch_scratch;
@@ -1931,8 +1970,10 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
 
 // n consecutive frames; batches of "batch_frames" frames per launch.  Debug views, single frames and
 // frames without samples take the one-frame path (nothing to overlap).
+static int render_single(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world);
 static int render_frames_impl(rt_handle* h, const rt_params* params, uint32_t n_frames, uint32_t rank, uint32_t world) {
     if (!h || !params) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_frames == 1) return render_single(h, params, rank, world);  // (one frame per call: rt_render's path)
     rt_params p = *params;
     uint32_t done = 0;
     // batches of equal size (20 frames at 16 per launch: 10 + 10, not 16 + 4)
@@ -1951,14 +1992,134 @@ static int render_frames_impl(rt_handle* h, const rt_params* params, uint32_t n_
     return RT_OK;
 }
 
-int rt_render(rt_handle* h, const rt_params* params) { return render_impl(h, params, 0, 1); }
+// ---- one frame per call, frames rendered ahead (option "frame_ahead") ---------------------------------------------
+static bool same_frame_params(const rt_params& a, const rt_params& b, int32_t b_frames) {  // (the padding is not compared)
+    return a.width == b.width && a.height == b.height && a.number_of_bounces == b.number_of_bounces &&
+           a.rays_per_pixel == b.rays_per_pixel && a.skybox == b.skybox && a.frames == b_frames && a.accumulate == b.accumulate &&
+           a.debug_flag == b.debug_flag && a.debug_scale == b.debug_scale;
+}
+
+// How many frames a call that continues an accumulation renders at once (0: just its own).  Automatic: only for scenes
+// staged in LDS (rays of known cost) and shares so small that a launch of their own leaves lanes idle -- in units of a
+// config-2 frame (1920 x 1080, 8 spp, 5 segments: 1.13 ms), batches of about 4 ms: 28 frames for a strip share of eight
+// ranks (0.201 ms per frame pipelined -> 0.16), 14 for one of four (0.404 -> 0.30), 7 for one of two (0.647 -> 0.59),
+// and none for the whole frame, whose pipelined launches (1.15 ms) a batch of three (1.2 ms) does not beat
+// (tools/strip_scaling.py, profiles/r04_strip_scaling.txt) -- unless the call finds the handle's stream idle: a host
+// that renders, waits, renders has no frames in flight for a pipeline to overlap, and even a batch of two or three keeps
+// the lanes fuller than lone launches do (config 2: 1.42 ms per lone frame).
+static uint32_t ahead_depth(const rt_handle* h, const rt_params* params, uint64_t need_texels, bool stream_idle) {
+    if (params->debug_flag != 0 || params->rays_per_pixel <= 0 || h->count_tests != 0 || params->frames < 1) return 0;
+    if (h->frame_ahead >= 0) return h->frame_ahead >= 2 ? std::min<uint32_t>((uint32_t)h->frame_ahead, RT_MAX_BATCH_FRAMES) : 0u;
+    if (h->frame_ahead_failed || !h->lds_scene || h->force_global) return 0;
+    const double segments = (double)need_texels * (double)params->rays_per_pixel *
+                            (double)((params->number_of_bounces < 0 ? 0 : params->number_of_bounces) + 1);
+    const double ms = segments / (1920.0 * 1080.0 * 8.0 * 5.0) * 1.13;
+    const double d = 4.0 / (ms > 1e-3 ? ms : 1e-3);
+    const uint32_t n = d >= (double)RT_MAX_BATCH_FRAMES ? RT_MAX_BATCH_FRAMES : (uint32_t)d;
+    return n >= (stream_idle ? 2u : 6u) ? n : 0u;
+}
+
+// blend slot `slot` of the frames rendered ahead into the image: wgsl:157-158 with the frame's own weight
+static int blend_ahead_slot(rt_handle* h, uint32_t slot, int32_t frames) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = wait_pending_copy(h); rc != RT_OK) return rc;
+    BlendArgs b{};
+    b.image = h->image;
+    b.scratch = h->batch_scratch + (size_t)slot * h->ahead.texels;
+    b.texels = h->ahead.texels;
+    b.stride = h->ahead.texels;
+    b.n = 1;
+    b.frames0 = frames;
+    {
+        volatile float w = 1.0f / (float)(int32_t)((uint32_t)frames + 1u);
+        volatile float r = 1.0f - w;
+        b.weight[0] = w;
+        b.rest[0] = r;
+    }
+    HIP_TRY(h, launch_blend_frames(b, h->stream));
+    if (h->pipe_stream[0]) {  // (pipelined frames may follow: their blends are ordered behind this one)
+        HIP_TRY(h, hipEventRecord(h->pipe_main, h->stream));
+        h->pipe_main_set = true;
+        h->pipe_main_need = true;
+    }
+    return RT_OK;
+}
+
+static int render_single(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world) {
+    if (!h || !params) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
+    auto remember = [&]() {
+        h->last_single.valid = true;
+        h->last_single.params = *params;
+        h->last_single.rank = rank;
+        h->last_single.world = world;
+        h->last_single.generation = h->generation;
+    };
+    if (h->ahead.valid) {
+        const int32_t want = (int32_t)((uint32_t)h->ahead.base.frames + h->ahead.next);
+        if (h->ahead.generation == h->generation && h->ahead.rank == rank && h->ahead.world == world &&
+            same_frame_params(*params, h->ahead.base, want)) {
+            const int rc = blend_ahead_slot(h, h->ahead.next, params->frames);
+            if (rc != RT_OK) {
+                h->ahead.valid = false;
+                return rc;
+            }
+            h->ahead.next += 1;
+            if (h->ahead.next == h->ahead.n) h->ahead.valid = false;
+            remember();
+            return RT_OK;
+        }
+        h->ahead.valid = false;  // the host went another way: what is left of the batch is dropped (it was never blended)
+        h->ahead_ramp = 2;
+    }
+    const bool continues = h->last_single.valid && h->last_single.generation == h->generation &&
+                           h->last_single.rank == rank && h->last_single.world == world &&
+                           same_frame_params(*params, h->last_single.params, (int32_t)((uint32_t)h->last_single.params.frames + 1u));
+    if (continues && h->have_scene && world != 0 && rank < world && params->width != 0 && params->height != 0) {
+        const uint64_t need_texels = world == 1 ? (uint64_t)params->width * params->height
+                                                : rt_strip_texels(params->width, params->height, rank, world);
+        const bool stream_idle = h->frame_ahead < 0 && hipSetDevice(h->device) == hipSuccess && hipStreamQuery(h->stream) == hipSuccess;
+        uint32_t d = ahead_depth(h, params, need_texels, stream_idle);
+        if (h->frame_ahead < 0 && d >= 2) {
+            if (d > h->ahead_ramp) d = h->ahead_ramp;
+            h->ahead_ramp = h->ahead_ramp >= RT_MAX_BATCH_FRAMES / 2 ? RT_MAX_BATCH_FRAMES : h->ahead_ramp * 2;
+        }
+        if (d >= 2 && need_texels <= h->image_texels) {
+            int rc = render_impl(h, params, rank, world, d, true);
+            if (rc == RT_OK) {
+                h->ahead.valid = true;
+                h->ahead.base = *params;
+                h->ahead.n = d;
+                h->ahead.next = 0;
+                h->ahead.rank = rank;
+                h->ahead.world = world;
+                h->ahead.generation = h->generation;
+                h->ahead.texels = need_texels;
+                rc = blend_ahead_slot(h, 0, params->frames);
+                h->ahead.next = 1;
+                if (rc != RT_OK) h->ahead.valid = false;
+                else remember();
+                return rc;
+            }
+            // (no room for the batch: this handle renders its frames one by one from now on)
+            if (h->frame_ahead < 0) h->frame_ahead_failed = true;
+            (void)hipGetLastError();
+        }
+    }
+    if (!continues) h->ahead_ramp = 2;
+    const int rc = render_impl(h, params, rank, world);
+    if (rc == RT_OK) remember();
+    else h->last_single.valid = false;
+    return rc;
+}
+
+int rt_render(rt_handle* h, const rt_params* params) { return render_single(h, params, 0, 1); }
 
 int rt_render_frames(rt_handle* h, const rt_params* params, uint32_t n_frames) {
     return render_frames_impl(h, params, n_frames, 0, 1);
 }
 
 int rt_render_strips(rt_handle* h, const rt_params* params, uint32_t rank, uint32_t world) {
-    return render_impl(h, params, rank, world);
+    return render_single(h, params, rank, world);
 }
 
 int rt_render_strips_frames(rt_handle* h, const rt_params* params, uint32_t n_frames, uint32_t rank, uint32_t world) {
@@ -2179,6 +2340,7 @@ int rt_write_image(rt_handle* h, const float* in, size_t bytes) {
     if (!h || !in) return fail(h, RT_ERR_INVALID_ARGUMENT, "null argument");
     if (bytes > h->image_texels * sizeof(float4))
         return fail(h, RT_ERR_INVALID_ARGUMENT, "write larger than the image");
+    h->generation += 1;
     HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = wait_pending_copy(h); rc != RT_OK) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->image, in, bytes, hipMemcpyHostToDevice, h->stream));
@@ -2234,6 +2396,7 @@ int rt_reset_timing(rt_handle* h) {
 
 int rt_set_stream(rt_handle* h, void* hip_stream) {
     if (!h) return RT_ERR_INVALID_ARGUMENT;
+    h->generation += 1;
     HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = wait_pending_copy(h); rc != RT_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -2245,6 +2408,7 @@ int rt_set_stream(rt_handle* h, void* hip_stream) {
 
 int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels) {
     if (!h) return RT_ERR_INVALID_ARGUMENT;
+    h->generation += 1;
     HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = wait_pending_copy(h); rc != RT_OK) return rc;  // (the caller may free the old buffer after this call)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -2346,7 +2510,8 @@ int rt_test_read_wavefront(rt_handle* h, int which, void* out, uint64_t bytes) {
         case 1: src = h->wf_hit; have = blocks * WF_HIT_PLANES * 64 * sizeof(float4); break;
         case 2: src = h->wf_lists; have = 2 * h->wf_capacity * sizeof(uint32_t); break;
         case 3: src = h->wf_counts; have = h->wf_counts_capacity * sizeof(uint32_t); break;
-        default: return fail(h, RT_ERR_INVALID_ARGUMENT, "which must be 0..3");
+        case 4: src = h->park_counts; have = h->park_counts ? 72 * sizeof(uint32_t) : 0; break;
+        default: return fail(h, RT_ERR_INVALID_ARGUMENT, "which must be 0..4");
     }
     if (!src || bytes > have) return fail(h, RT_ERR_INVALID_ARGUMENT, "no wavefront buffer of that size");
     HIP_TRY(h, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, h->stream));

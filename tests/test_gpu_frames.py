@@ -12,10 +12,14 @@ pytestmark = pytest.mark.gpu
 
 
 def sequential(rt, tracer, w, h, bounces, spp, f0, n, start=None):
-    tracer.write_image(np.zeros((h, w, 4), np.float32) if start is None else start)
-    for f in range(f0, f0 + n):
-        tracer.render(rt.make_params(w, h, bounces, spp, skybox=1, frames=f))
-    return tracer.read_image(w, h)
+    tracer.set_option("frame_ahead", 0)   # (one launch per frame: the plain path is the yardstick)
+    try:
+        tracer.write_image(np.zeros((h, w, 4), np.float32) if start is None else start)
+        for f in range(f0, f0 + n):
+            tracer.render(rt.make_params(w, h, bounces, spp, skybox=1, frames=f))
+        return tracer.read_image(w, h)
+    finally:
+        tracer.set_option("frame_ahead", -1)
 
 
 @pytest.fixture(scope="module")
@@ -91,6 +95,7 @@ def test_segments_reused_is_exact(rt, tracer, cornell, variant, lds, batch):
     tracer.load_scene(cornell)
     tracer.set_option("kernel_variant", variant)
     tracer.set_option("lds_scene", lds)
+    tracer.set_option("frame_ahead", 0)   # (the counters count what was launched: exactly these frames, one launch each)
     got = {}
     try:
         for hits in (1, 0):
@@ -108,6 +113,7 @@ def test_segments_reused_is_exact(rt, tracer, cornell, variant, lds, batch):
         tracer.set_option("lds_scene", 1)
         tracer.set_option("batch_frames", 16)
         tracer.set_option("primary_hits", 1)
+        tracer.set_option("frame_ahead", -1)
     s, s0 = got[1][0], got[0][0]
     assert s.segments_reused == w * h * spp * frames and s0.segments_reused == w * h * (spp - 1) * frames
     assert s.segments == s0.segments and np.array_equal(bits(got[1][1]), bits(got[0][1]))
@@ -396,11 +402,15 @@ def test_timing_survives_the_event_pool_wrap(rt, tracer, cornell):
     """More launches than the event pool holds: launches, frames, paths and kernel_ms keep counting."""
     w, h = 8, 8
     tracer.load_scene(cornell)
-    tracer.reset_timing()
-    n = 4096 + 50
-    for f in range(n):
-        tracer.render(rt.make_params(w, h, 1, 1, frames=f))
-    st = tracer.stats()
+    tracer.set_option("frame_ahead", 0)   # (one launch per frame)
+    try:
+        tracer.reset_timing()
+        n = 4096 + 50
+        for f in range(n):
+            tracer.render(rt.make_params(w, h, 1, 1, frames=f))
+        st = tracer.stats()
+    finally:
+        tracer.set_option("frame_ahead", -1)
     assert st.launches == n and st.frames == n and st.paths == 64 * n
     assert st.kernel_ms > 0 and st.kernel_ms / n < 5.0
 
@@ -472,6 +482,7 @@ def test_pipelined_single_frames(rt, oracle, tracer, cornell):
 
     tracer.load_scene(cornell)
     try:
+        tracer.set_option("frame_ahead", 0)   # (every frame a launch of its own: this test is about those)
         tracer.set_option("pipeline", 0)
         want = script(tracer)
         # (pipeline_when_idle = 1: frames this small are over before the next call arrives, and a frame that finds the
@@ -487,10 +498,76 @@ def test_pipelined_single_frames(rt, oracle, tracer, cornell):
     finally:
         tracer.set_option("pipeline", 1)
         tracer.set_option("pipeline_when_idle", 0)
+        tracer.set_option("frame_ahead", -1)
     ref = np.zeros((h, w, 4), np.float32)
     for f in range(3):
         ref, _ = oracle.render(rt.make_params(w, h, 4, 3, skybox=1, frames=f), cornell, image=ref)
         assert np.array_equal(bits(got[f]), bits(ref)), f
+
+
+def test_frames_rendered_ahead_leave_the_same_image_after_every_call(rt, oracle, tracer, cornell):
+    """Option frame_ahead: a one-frame call that continues an accumulation renders the next frames with its own in one
+    batched launch and the following calls only blend theirs.  The image after EVERY call -- through a host that re-sends
+    the same camera each frame (the reference's update_buffers), a change of samples per pixel, a moved camera
+    (accumulation restarts), a skipped frame number, an image written by the host, a batch and a strip call in between,
+    a sequence longer than a batch -- equals the one-launch-per-frame run's, and the first frames equal the oracle's."""
+    w, h = 200, 104
+    cam_t = type(cornell.uniform.camera)
+
+    def script(t):
+        out = []
+
+        def frame(f, spp=3, ww=w, hh=h):
+            t.render(rt.make_params(ww, hh, 4, spp, skybox=1, frames=f))
+            out.append(t.read_image(ww, hh).copy())
+        t.write_image(np.zeros((h, w, 4), np.float32))
+        for f in range(12):
+            if f % 3 == 0:
+                t.set_camera(cam_t.from_buffer_copy(bytes(cornell.uniform.camera)))   # the same camera again
+            frame(f)
+        frame(12, spp=2)                                         # other parameters: what was rendered ahead is dropped
+        for f in range(13, 16):
+            frame(f, spp=2)
+        cam = cam_t.from_buffer_copy(bytes(cornell.uniform.camera))
+        cam.cam_to_world[3][0] += 0.05
+        t.set_camera(cam)                                        # accumulation restarts
+        for f in range(5):
+            frame(f)
+        frame(7)                                                 # a frame number skipped
+        frame(8)
+        t.write_image(out[3])                                    # the host restores an earlier image
+        for f in range(9, 12):
+            frame(f)
+        t.render_frames(rt.make_params(w, h, 4, 3, skybox=1, frames=12), 5)   # an explicit batch in between
+        for f in range(17, 20):
+            frame(f)
+        t.render_strips(rt.make_params(w, h, 4, 3, skybox=1, frames=20), 1, 4)   # (a strip share overwrites the image's head)
+        out.append(t.read_texels(t.strip_texels(w, h, 1, 4)).copy())
+        for f in range(40):                                      # longer than any batch; no read in between
+            t.render(rt.make_params(96, 54, 3, 2, skybox=1, frames=f))
+        out.append(t.read_image(96, 54).copy())
+        t.set_camera(cornell.uniform.camera)
+        return out
+
+    tracer.load_scene(cornell)
+    try:
+        tracer.set_option("frame_ahead", 0)
+        want = script(tracer)
+        for ahead in (-1, 2, 5, 32):
+            tracer.set_option("frame_ahead", ahead)
+            tracer.reset_timing()
+            got = script(tracer)
+            st = tracer.stats()
+            assert len(got) == len(want)
+            for k, (g, wnt) in enumerate(zip(got, want)):
+                assert np.array_equal(bits(g), bits(wnt)), (ahead, k)
+            assert st.launches < st.frames   # (frames were rendered ahead: fewer launches than frames)
+    finally:
+        tracer.set_option("frame_ahead", -1)
+    ref = np.zeros((h, w, 4), np.float32)
+    for f in range(3):
+        ref, _ = oracle.render(rt.make_params(w, h, 4, 3, skybox=1, frames=f), cornell, image=ref)
+        assert np.array_equal(bits(want[f]), bits(ref)), f
 
 
 def test_pipelined_single_frames_global_memory_scene(rt, tracer):

@@ -211,7 +211,20 @@ def test_config2_whole_frame_accumulated(rt, oracle, tracer, cornell):
         want_rays += st.segments
         tracer.render(p)
         assert np.array_equal(bits(tracer.read_image(W, H)), bits(ref)), f
-    assert tracer.stats().segments == want_rays
+    # (default options: a call that continues the accumulation and finds the stream idle renders the next frames with
+    # its own -- option frame_ahead; the counters count what was launched)
+    st = tracer.stats()
+    assert st.segments >= want_rays and st.launches < NF
+    tracer.set_option("frame_ahead", 0)   # one launch per frame: exactly these rays
+    try:
+        tracer.write_image(np.zeros((H, W, 4), np.float32))
+        tracer.reset_timing()
+        for f in range(NF):
+            tracer.render(rt.make_params(W, H, 4, 8, frames=f))
+        assert np.array_equal(bits(tracer.read_image(W, H)), bits(ref))
+        assert tracer.stats().segments == want_rays and tracer.stats().launches == NF
+    finally:
+        tracer.set_option("frame_ahead", -1)
     tracer.write_image(np.zeros((H, W, 4), np.float32))
     tracer.reset_timing()
     tracer.render_frames(rt.make_params(W, H, 4, 8, frames=0), NF)
