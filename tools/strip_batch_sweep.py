@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Rank 0's share of the config-2 frame at world = 1, 2, 4, 8 in back-to-back batched launches of 2 .. 32 frames (no
+pipeline): how many frames a launch needs before the persistent kernel's lane refill pays -- the figures behind the
+automatic depth of option frame_ahead (rt_api.hip: ahead_depth).  profiles/r04_strip_batch_sweep.txt."""
 import os, statistics, sys, time
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ray_tracer_2_amd as rt
 W, H, N = 1920, 1080, 64
