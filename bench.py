@@ -320,6 +320,36 @@ def main():
             tracer.set_option("pipeline_when_idle", 0)
             tracer.set_option("frame_ahead", -1)
         extras["ms_per_frame_render_then_wait"] = present
+        # A host that SHOWS every frame (the reference blits its storage texture every redraw) has to bring the 33 MB frame to
+        # the host: render, rt_read_image, render, ... against rt_snapshot_image (device copy in stream order) +
+        # rt_read_snapshot (the host copy on a stream of its own, while the next frame renders).  PCIe-inclusive: never `value`.
+        shown = {}
+        host_frame = np.empty((H, W, 4), np.float32)
+        host_frame[:] = 0
+        for name in ("render_then_read_image", "snapshot_read_under_next_frame"):
+            ts = []
+            for rep in range(3):
+                tracer.synchronize()
+                t1 = time.perf_counter()
+                n_shown = 48
+                tracer.render(rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=1))
+                if name.startswith("snapshot"):
+                    tracer.snapshot_image(W, H)
+                for f in range(1, n_shown):
+                    if name.startswith("snapshot"):
+                        tracer.render(rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=1 + f))
+                        tracer._check(tracer._L.rt_read_snapshot(tracer._h, host_frame.ctypes.data, host_frame.nbytes))
+                        tracer.snapshot_image(W, H)
+                    else:
+                        tracer._check(tracer._L.rt_read_image(tracer._h, host_frame.ctypes.data, host_frame.nbytes))
+                        tracer.render(rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=1 + f))
+                if name.startswith("snapshot"):
+                    tracer._check(tracer._L.rt_read_snapshot(tracer._h, host_frame.ctypes.data, host_frame.nbytes))
+                else:
+                    tracer._check(tracer._L.rt_read_image(tracer._h, host_frame.ctypes.data, host_frame.nbytes))
+                ts.append((time.perf_counter() - t1) / n_shown * 1e3)
+            shown[name] = statistics.median(ts)
+        extras["ms_per_shown_frame_pcie_inclusive"] = shown
         # first frame after a camera change at full size: natural tile order, primary-ray table rebuilt
         cam_t = type(arrays.uniform.camera)
         cam0 = cam_t.from_buffer_copy(bytes(arrays.uniform.camera))

@@ -104,6 +104,16 @@ class RayTracer:
         self._check(self._L.rt_read_image(self._h, out.ctypes.data, out.nbytes))
         return out
 
+    def snapshot_image(self, width, height):
+        """Keep the image as it is now aside (stream-ordered device copy; does not block)."""
+        self._check(self._L.rt_snapshot_image(self._h, width * height * 16))
+
+    def read_snapshot(self, width, height):
+        """The last snapshot, read on a stream of its own: later frames are not waited for."""
+        out = np.empty((height, width, 4), dtype=np.float32)
+        self._check(self._L.rt_read_snapshot(self._h, out.ctypes.data, out.nbytes))
+        return out
+
     def write_image(self, img):
         img = np.ascontiguousarray(img, dtype=np.float32)
         self._check(self._L.rt_write_image(self._h, img.ctypes.data, img.nbytes))

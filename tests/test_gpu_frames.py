@@ -592,3 +592,41 @@ def test_pipelined_single_frames_global_memory_scene(rt, tracer):
             tracer.set_option("pipeline_when_idle", 0)
         for o in outs[1:]:
             assert np.array_equal(bits(outs[0][0]), bits(o[0])) and outs[0][1] == o[1]
+
+
+def test_snapshot_is_the_frame_of_its_call_while_later_frames_render(rt, cornell):
+    """rt_snapshot_image / rt_read_snapshot: the snapshot taken behind frame k is frame k -- bit for bit -- although
+    frames k + 1.. were queued before it was read (the reference's host shows every frame: src/rendering/renderer.rs),
+    under pipelined launches, frames rendered ahead and with both off; it can be read twice and in part."""
+    w, h, n = 320, 180, 9
+    t = rt.RayTracer(0, w, h)
+    with pytest.raises(rt.RtError):
+        t.read_snapshot(w, h)                                   # nothing taken yet
+    t.load_scene(cornell)
+    with pytest.raises(rt.RtError):
+        t.snapshot_image(w + 1, h)                              # larger than the image
+    t.set_option("frame_ahead", 0)
+    t.set_option("pipeline", 0)
+    want = []
+    for f in range(n):
+        t.render(rt.make_params(w, h, 4, 3, skybox=1, frames=f))
+        want.append(t.read_image(w, h).copy())
+    for ahead, pipe in ((0, 0), (0, 4), (-1, 1), (4, 1)):
+        t.set_option("frame_ahead", ahead)
+        t.set_option("pipeline", pipe)
+        t.write_image(np.zeros((h, w, 4), np.float32))
+        got = []
+        t.render(rt.make_params(w, h, 4, 3, skybox=1, frames=0))
+        t.snapshot_image(w, h)
+        for f in range(1, n):
+            t.render(rt.make_params(w, h, 4, 3, skybox=1, frames=f))   # queued before frame f - 1 is read
+            got.append(t.read_snapshot(w, h))
+            if f == 3:
+                assert np.array_equal(bits(t.read_snapshot(w, h)), bits(got[-1]))                 # twice
+                assert np.array_equal(bits(t.read_snapshot(w, h // 2)), bits(got[-1][: h // 2]))   # in part
+            t.snapshot_image(w, h)
+        got.append(t.read_snapshot(w, h))
+        for f in range(n):
+            assert np.array_equal(bits(got[f]), bits(want[f])), (ahead, pipe, f)
+        assert np.array_equal(bits(t.read_image(w, h)), bits(want[-1]))
+    t.close()
