@@ -79,6 +79,8 @@ int RayTracer::update_buffers(Scene& scene) {
 
 int RayTracer::render(const rt_params& params) { return h_ ? rt_render(h_, &params) : RT_ERR_INVALID_ARGUMENT; }
 int RayTracer::read_image(float* rgba, size_t bytes) { return h_ ? rt_read_image(h_, rgba, bytes) : RT_ERR_INVALID_ARGUMENT; }
+int RayTracer::snapshot_image(size_t bytes) { return h_ ? rt_snapshot_image(h_, bytes) : RT_ERR_INVALID_ARGUMENT; }
+int RayTracer::read_snapshot(float* rgba, size_t bytes) { return h_ ? rt_read_snapshot(h_, rgba, bytes) : RT_ERR_INVALID_ARGUMENT; }
 int RayTracer::stats(rt_stats* out) { return h_ ? rt_get_stats(h_, out) : RT_ERR_INVALID_ARGUMENT; }
 const char* RayTracer::last_error() const { return rt_last_error(h_); }
 

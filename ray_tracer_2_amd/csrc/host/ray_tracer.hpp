@@ -41,6 +41,9 @@ class RayTracer {
     int render(const rt_params& params);
     // ≙ the texture->buffer copy of save_render_to_file (app.rs:341-407).
     int read_image(float* rgba32f, size_t bytes);
+    // the display path (include/rt_abi.h): keep the frame just rendered aside, fetch it after the next render was queued
+    int snapshot_image(size_t bytes);
+    int read_snapshot(float* rgba32f, size_t bytes);
     int stats(rt_stats* out);
     const char* last_error() const;
     rt_handle* handle() const { return h_; }

@@ -8,6 +8,7 @@
 // tests/test_gpu_cpp_class.py: on this GPU pool a process that has initialised the GPU must not exec
 // another program, so the "test program" is a library with one entry point instead of an executable.
 #include <cstdio>
+#include <vector>
 #include <cstring>
 #include <string>
 
@@ -75,6 +76,12 @@ extern "C" int rt2_class_driver(const char* scene_name, const char* assets_dir, 
         }
     }
     CHECK(tracer.read_image(rgba32f_out, (size_t)width * height * 16) == RT_OK);
+    {   // the display path returns the same frame
+        std::vector<float> snap((size_t)width * height * 4);
+        CHECK(tracer.snapshot_image(snap.size() * 4) == RT_OK);
+        CHECK(tracer.read_snapshot(snap.data(), snap.size() * 4) == RT_OK);
+        CHECK(std::memcmp(snap.data(), rgba32f_out, snap.size() * 4) == 0);
+    }
     rt_stats st;
     CHECK(tracer.stats(&st) == RT_OK);
     // (a call that continues an accumulation may render the next frames with its own: option "frame_ahead")
