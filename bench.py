@@ -97,6 +97,66 @@ def cpu_baseline(rt, arrays):
             "sample": f"{what} of the same workload ({seg} rays in {t:.1f} s); CPU restatement of ray_tracer.wgsl, not wgpu/lavapipe"}
 
 
+def live_traffic(args):
+    """HBM bytes per launch of the render (+ blend) kernel, measured IN THIS RUN: two child runs of this script's timed loop
+    under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE each in a pass of its own, converted as MI355X_MICROARCH.md
+    prescribes (KiB; FETCH_SIZE x 2 on gfx950) -- started BEFORE this process touches the GPU (a process that has
+    initialised HIP must not start programs on this pool; the children are ordinary processes of their own).
+    Returns (record, None) or (None, reason); the committed profile (profiles/latest_traffic.json) is the fallback."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    # (the product library must exist before the profiler starts: no compile under rocprofv3)
+    from ray_tracer_2_amd import build
+    if not os.path.exists(build.PRODUCT_SO):
+        return None, "product library not built"
+    frames = 32
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "64", "--warmup", "32", "--batch", str(frames),
+             "--width", str(args.width), "--height", str(args.height),
+             "--no-cpu-baseline", "--no-extras", "--no-per-frame-leg", "--no-live-traffic"]
+    out = tempfile.mkdtemp(prefix="rt2_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            try:
+                r = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", *child], cwd="/tmp", env=env,
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter}: no result within 300 s"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter}: exit {r.returncode}: " + r.stderr.decode(errors="replace")[-200:]
+            rows = []
+            for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                rows += list(csv.DictReader(open(path)))
+            rows = [x for x in rows if x.get("Counter_Name") == counter]
+            if rows and "Dispatch_Id" in rows[0]:
+                rows.sort(key=lambda x: int(x["Dispatch_Id"]))
+            names = collections.Counter(x["Kernel_Name"] for x in rows if "rt_render" in x["Kernel_Name"])
+            if not names:
+                return None, f"rocprofv3 --pmc {counter}: no render kernel in the counter file"
+            name = names.most_common(1)[0][0]
+            v = [float(x["Counter_Value"]) for x in rows if x["Kernel_Name"] == name]
+            v = v[1:] if len(v) > 2 else v          # (launches after the first, as profiles/summarize.py)
+            b = [float(x["Counter_Value"]) for x in rows if "rt_blend" in x["Kernel_Name"]]
+            sums[counter] = (sum(v) / len(v), sum(b) / len(b) if b else 0.0, len(v), name)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    fetch = (sums["FETCH_SIZE"][0] + sums["FETCH_SIZE"][1]) * 1024 * 2   # KiB -> B, gfx950: x 2
+    write = (sums["WRITE_SIZE"][0] + sums["WRITE_SIZE"][1]) * 1024
+    return {"bytes_per_launch": fetch + write, "frames_per_launch": frames, "read_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+            "source": f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each, over `bench.py --steps 64 --warmup 32 "
+                      f"--batch {frames}` ({sums['FETCH_SIZE'][2]} launches of {sums['FETCH_SIZE'][3][:60]} after the first, plus the blend kernel); "
+                      "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (MI355X_MICROARCH.md)"}, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +170,8 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU-staged rehearsal on one GPU)")
     ap.add_argument("--batch", type=int, default=32, help="frames per launch of rt_render_frames (1..32; 1 = one launch per frame)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short child runs under rocprofv3 --pmc); use the committed profile")
     ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning; default: library default)")
     ap.add_argument("--blocks", type=int, default=None, help="persistent grid size (tuning)")
     args = ap.parse_args()
@@ -130,6 +192,13 @@ def main():
         sys.exit(subprocess.run(cmd).returncode)
     if world != args.gpus:
         args.gpus = world
+    live, live_error = None, None
+    if world == 1 and "WORLD_SIZE" not in os.environ and not args.no_live_traffic and args.variant is None and args.blocks is None \
+            and not os.environ.get("RT2_OPTIONS") and args.batch > 1:
+        try:
+            live, live_error = live_traffic(args)   # (before this process touches the GPU)
+        except Exception as e:  # noqa: BLE001 -- the bench line must not depend on the profiler
+            live, live_error = None, f"{type(e).__name__}: {e}"
 
     import torch
     import ray_tracer_2_amd as rt
@@ -399,6 +468,10 @@ def main():
         # are reported only when they were measured on the build that is running (source hash, batch).
         traffic, traffic_src, valu, stale = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        if live is not None and frames_per_launch > 1:
+            traffic = live["bytes_per_launch"] * frames_per_launch / live["frames_per_launch"]
+            traffic_src = live["source"] + (f"; per frame x {frames_per_launch:g} frames per launch"
+                                            if frames_per_launch != live["frames_per_launch"] else "")
         if world == 1 and (W, H) == (WIDTH, HEIGHT) and os.path.exists(tpath):
             from ray_tracer_2_amd.build import source_hash
             tj = json.load(open(tpath))
@@ -409,8 +482,9 @@ def main():
                 # counters are kept per frame (they do not depend on how many frames share a launch) and
                 # scaled to this run's frames per launch
                 scale = frames_per_launch / tj.get("frames_per_launch", 1)
-                traffic = tj["bytes_per_launch"] * scale
-                traffic_src = tj["source"] + (f", per frame x {frames_per_launch:g} frames per launch" if scale != 1 else "")
+                if traffic is None:   # (not measured in this run: the committed profile of the same sources)
+                    traffic = tj["bytes_per_launch"] * scale
+                    traffic_src = tj["source"] + (f", per frame x {frames_per_launch:g} frames per launch" if scale != 1 else "")
                 if "valu_instructions_per_launch" in tj:
                     # The bound that matters: VALU issue.  Peak = the guide's: a SIMD-32
                     # issues one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md; that is what
@@ -475,6 +549,7 @@ def main():
                        "Mpaths/s": W * H * SPP * args.steps / elapsed / 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src or stale,
+                         "traffic_measured_in_this_run": live is not None and traffic is not None, "traffic_live_error": live_error,
                          "kernel": kernel, "kernel_ms": launch_ms, "frames_per_launch": frames_per_launch,
                          "launch": launch_info,
                          "algorithmic_bytes_per_launch": algo_bytes,
