@@ -123,35 +123,59 @@ def live_traffic(args):
     out = tempfile.mkdtemp(prefix="rt2_traffic_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     sums = {}
+
+    def one_pass(tag, counters):
+        """{counter: (render mean per launch, blend mean per launch, launches, kernel, mean render launch seconds)} or a reason"""
+        d = os.path.join(out, tag)
+        try:
+            r = subprocess.run([prof, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", *child], cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        except subprocess.TimeoutExpired:
+            return f"rocprofv3 --pmc {' '.join(counters)}: no result within 300 s"
+        if r.returncode != 0:
+            return f"rocprofv3 --pmc {' '.join(counters)}: exit {r.returncode}: " + r.stderr.decode(errors="replace")[-200:]
+        rows = []
+        for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            rows += list(csv.DictReader(open(path)))
+        if rows and "Dispatch_Id" in rows[0]:
+            rows.sort(key=lambda x: int(x["Dispatch_Id"]))
+        names = collections.Counter(x["Kernel_Name"] for x in rows if "rt_render" in x["Kernel_Name"])
+        if not names:
+            return f"rocprofv3 --pmc {' '.join(counters)}: no render kernel in the counter file"
+        name = names.most_common(1)[0][0]
+        res = {}
+        for counter in counters:
+            mine = [x for x in rows if x.get("Counter_Name") == counter and x["Kernel_Name"] == name]
+            if not mine:
+                return f"rocprofv3 --pmc: no {counter} rows for the render kernel"
+            mine = mine[1:] if len(mine) > 2 else mine          # (launches after the first, as profiles/summarize.py)
+            v = [float(x["Counter_Value"]) for x in mine]
+            secs = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) * 1e-9 for x in mine] if "End_Timestamp" in mine[0] else [0.0]
+            b = [float(x["Counter_Value"]) for x in rows if x.get("Counter_Name") == counter and "rt_blend" in x["Kernel_Name"]]
+            res[counter] = (sum(v) / len(v), sum(b) / len(b) if b else 0.0, len(v), name, sum(secs) / len(secs))
+        return res
+
+    valu, valu_error = None, None
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(out, counter)
-            try:
-                r = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", *child], cwd="/tmp", env=env,
-                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-            except subprocess.TimeoutExpired:
-                return None, f"rocprofv3 --pmc {counter}: no result within 300 s"
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter}: exit {r.returncode}: " + r.stderr.decode(errors="replace")[-200:]
-            rows = []
-            for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
-                rows += list(csv.DictReader(open(path)))
-            rows = [x for x in rows if x.get("Counter_Name") == counter]
-            if rows and "Dispatch_Id" in rows[0]:
-                rows.sort(key=lambda x: int(x["Dispatch_Id"]))
-            names = collections.Counter(x["Kernel_Name"] for x in rows if "rt_render" in x["Kernel_Name"])
-            if not names:
-                return None, f"rocprofv3 --pmc {counter}: no render kernel in the counter file"
-            name = names.most_common(1)[0][0]
-            v = [float(x["Counter_Value"]) for x in rows if x["Kernel_Name"] == name]
-            v = v[1:] if len(v) > 2 else v          # (launches after the first, as profiles/summarize.py)
-            b = [float(x["Counter_Value"]) for x in rows if "rt_blend" in x["Kernel_Name"]]
-            sums[counter] = (sum(v) / len(v), sum(b) / len(b) if b else 0.0, len(v), name)
+            got = one_pass(counter, [counter])
+            if isinstance(got, str):
+                return None, got
+            sums.update(got)
+        # (a third pass for the bound that matters -- VALU issue; its failure does not void the traffic)
+        got = one_pass("valu", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"])
+        if isinstance(got, str):
+            valu_error = got
+        else:
+            secs = got["GRBM_GUI_ACTIVE"][4]
+            valu = {"valu_instructions_per_launch": got["SQ_INSTS_VALU"][0],
+                    "valu_lane_utilisation": got["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * got["SQ_ACTIVE_INST_VALU"][0]),
+                    "shader_clock_ghz": got["GRBM_GUI_ACTIVE"][0] / 8.0 / secs / 1e9 if secs > 0 else None}
     finally:
         shutil.rmtree(out, ignore_errors=True)
     fetch = (sums["FETCH_SIZE"][0] + sums["FETCH_SIZE"][1]) * 1024 * 2   # KiB -> B, gfx950: x 2
     write = (sums["WRITE_SIZE"][0] + sums["WRITE_SIZE"][1]) * 1024
-    return {"bytes_per_launch": fetch + write, "frames_per_launch": frames, "read_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+    return {"valu": valu, "valu_error": valu_error, "bytes_per_launch": fetch + write, "frames_per_launch": frames, "read_bytes_per_launch": fetch, "write_bytes_per_launch": write,
             "source": f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each, over `bench.py --steps 64 --warmup 32 "
                       f"--batch {frames}` ({sums['FETCH_SIZE'][2]} launches of {sums['FETCH_SIZE'][3][:60]} after the first, plus the blend kernel); "
                       "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (MI355X_MICROARCH.md)"}, None
@@ -485,7 +509,7 @@ def main():
                 if traffic is None:   # (not measured in this run: the committed profile of the same sources)
                     traffic = tj["bytes_per_launch"] * scale
                     traffic_src = tj["source"] + (f", per frame x {frames_per_launch:g} frames per launch" if scale != 1 else "")
-                if "valu_instructions_per_launch" in tj:
+                if "valu_instructions_per_launch" in tj and not (live and live.get("valu")):
                     # The bound that matters: VALU issue.  Peak = the guide's: a SIMD-32
                     # issues one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md; that is what
                     # 157.3 TFLOP/s FP32 means).  issue_frac = wave-instructions issued / that peak;
@@ -502,6 +526,21 @@ def main():
                             "useful_lane_frac": (rate / peak * lanes) if lanes else None,
                             "measured_stream_peak": tj.get("measured_valu_stream_peak"),
                             "source": tj["source"].replace("FETCH_SIZE / WRITE_SIZE", "SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU / GRBM_GUI_ACTIVE")}
+        if live and live.get("valu") and frames_per_launch > 1:
+            lv = live["valu"]
+            simds = torch.cuda.get_device_properties(device).multi_processor_count * 4
+            clock = lv.get("shader_clock_ghz") or 2.4
+            rate = lv["valu_instructions_per_launch"] * frames_per_launch / live["frames_per_launch"] / (launch_ms * 1e-3) / 1e9
+            peak = simds * clock / 2.0
+            lanes = lv["valu_lane_utilisation"]
+            valu = {"bound": "valu_issue", "achieved": rate, "peak": peak, "unit": "G wave-instructions/s",
+                    "peak_definition": "MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles per SIMD-32 x "
+                                       f"{simds} SIMDs x {clock:.2f} GHz (shader clock measured in this run: GRBM_GUI_ACTIVE / 8 / kernel time)",
+                    "frac": rate / peak, "issue_frac": rate / peak, "lane_utilisation": lanes, "useful_lane_frac": rate / peak * lanes,
+                    "valu_instructions_per_frame": lv["valu_instructions_per_launch"] / live["frames_per_launch"],
+                    "measured_in_this_run": True,
+                    "source": "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE, one pass over "
+                              "the same child run as roofline.traffic; instructions per launch / this run's launch time"}
         # which kernel the library runs for this shape (rt_api.hip render_impl): batches always the persistent one
         cus = torch.cuda.get_device_properties(device).multi_processor_count
         tiles = ((W + 7) // 8) * (texels // W // 8 if world > 1 else (H + 7) // 8)
@@ -559,6 +598,8 @@ def main():
         }
         if valu is not None:
             out["roofline_valu"] = valu
+        if live is not None and live.get("valu_error"):
+            out["roofline_valu_live_error"] = live["valu_error"]
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, arrays)
