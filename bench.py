@@ -217,8 +217,11 @@ def main():
     if world != args.gpus:
         args.gpus = world
     live, live_error = None, None
+    # (never under a profiler: its preloaded tool library has initialised the GPU in THIS process already, and such a process
+    # must not start programs on this pool; never when torch has been imported by whoever runs this as a module)
+    profiled = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if world == 1 and "WORLD_SIZE" not in os.environ and not args.no_live_traffic and args.variant is None and args.blocks is None \
-            and not os.environ.get("RT2_OPTIONS") and args.batch > 1:
+            and not os.environ.get("RT2_OPTIONS") and args.batch > 1 and not profiled and "torch" not in sys.modules:
         try:
             live, live_error = live_traffic(args)   # (before this process touches the GPU)
         except Exception as e:  # noqa: BLE001 -- the bench line must not depend on the profiler
