@@ -354,7 +354,9 @@ def main():
         fence()
         elapsed_pf = time.perf_counter() - t1
         st_pf = tracer.stats()
-        rays_pf_local = float(st_pf.segments)
+        # (calls that continue the accumulation may have rendered frames beyond the window with their own -- option
+        # frame_ahead; the counters count what was launched: the window's share is rays per launched frame x its frames)
+        rays_pf_local = float(st_pf.segments) * args.steps / max(st_pf.frames, 1)
         launch_ms_pf = st_pf.kernel_ms / max(st_pf.launches, 1)
 
     if world > 1:
