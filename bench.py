@@ -127,13 +127,21 @@ def live_traffic(args):
     def one_pass(tag, counters):
         """{counter: (render mean per launch, blend mean per launch, launches, kernel, mean render launch seconds)} or a reason"""
         d = os.path.join(out, tag)
+        # (a process group of its own: on a timeout the profiler AND the program under it are ended, by that group's id)
+        proc = subprocess.Popen([prof, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", *child], cwd="/tmp", env=env,
+                                stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
         try:
-            r = subprocess.run([prof, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", *child], cwd="/tmp", env=env,
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            _, err = proc.communicate(timeout=300)
         except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            proc.communicate()
             return f"rocprofv3 --pmc {' '.join(counters)}: no result within 300 s"
-        if r.returncode != 0:
-            return f"rocprofv3 --pmc {' '.join(counters)}: exit {r.returncode}: " + r.stderr.decode(errors="replace")[-200:]
+        if proc.returncode != 0:
+            return f"rocprofv3 --pmc {' '.join(counters)}: exit {proc.returncode}: " + err.decode(errors="replace")[-200:]
         rows = []
         for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
             rows += list(csv.DictReader(open(path)))
