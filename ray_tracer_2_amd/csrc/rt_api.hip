@@ -2095,6 +2095,20 @@ static int render_single(rt_handle* h, const rt_params* params, uint32_t rank, u
         const bool stream_idle = h->frame_ahead < 0 && hipSetDevice(h->device) == hipSuccess && hipStreamQuery(h->stream) == hipSuccess;
         uint32_t d = ahead_depth(h, params, need_texels, stream_idle);
         if (h->frame_ahead < 0 && d >= 2) {
+            // (room for the full depth at once: the batches on the way up would each re-allocate the scratch images -- a
+            // stream synchronisation apiece)
+            if (h->batch_scratch_texels < need_texels * d && hipSetDevice(h->device) == hipSuccess &&
+                hipStreamSynchronize(h->stream) == hipSuccess) {
+                float4* bigger = nullptr;
+                if (hipMalloc((void**)&bigger, need_texels * d * sizeof(float4)) == hipSuccess) {
+                    free_dev(h->batch_scratch);
+                    h->batch_scratch = bigger;
+                    h->batch_scratch_texels = need_texels * d;
+                    h->scratch_w = 0;  // (new memory: render_impl zeroes it)
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
             if (d > h->ahead_ramp) d = h->ahead_ramp;
             h->ahead_ramp = h->ahead_ramp >= RT_MAX_BATCH_FRAMES / 2 ? RT_MAX_BATCH_FRAMES : h->ahead_ramp * 2;
         }
