@@ -397,7 +397,7 @@ int rt_test_device_sample_texture(rt_handle* h, const rt_texture_desc* tex, cons
 
 /* Test-only: raw copy of a buffer of the last wavefront sequence (which: 0 path state, 1 hit records, 2 the two slot
  * lists, 3 the per-round list counts; layouts in csrc/rt_device.h), or (which = 4) the pixels parked in front of each round
- * of the last deferred-walk sequence (72 u32). */
+ * of the last deferred-walk sequence (72 u32), or (which = 5, 6) the park records of its even / odd rounds. */
 int rt_test_read_wavefront(rt_handle* h, int which, void* out, uint64_t bytes);
 /* The grouped ncclSend / ncclRecv gather of rt_render_multi against the RCCL-shaped library at `lib_path`, on fake
  * buffers and without any HIP call (runs without a GPU): checks that a failure inside the group still closes the group

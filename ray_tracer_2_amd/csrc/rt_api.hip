@@ -2586,7 +2586,11 @@ int rt_test_read_wavefront(rt_handle* h, int which, void* out, uint64_t bytes) {
         case 2: src = h->wf_lists; have = 2 * h->wf_capacity * sizeof(uint32_t); break;
         case 3: src = h->wf_counts; have = h->wf_counts_capacity * sizeof(uint32_t); break;
         case 4: src = h->park_counts; have = h->park_counts ? 72 * sizeof(uint32_t) : 0; break;
-        default: return fail(h, RT_ERR_INVALID_ARGUMENT, "which must be 0..4");
+        case 5: case 6:   // the park records of the last sequence's even / odd rounds (rt_device.h: PARK_PLANES)
+            src = h->park_queue[which - 5];
+            have = src ? ((h->park_capacity + 63) / 64) * (size_t)PARK_PLANES * 64u * sizeof(float4) : 0;
+            break;
+        default: return fail(h, RT_ERR_INVALID_ARGUMENT, "which must be 0..6");
     }
     if (!src || bytes > have) return fail(h, RT_ERR_INVALID_ARGUMENT, "no wavefront buffer of that size");
     HIP_TRY(h, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, h->stream));

@@ -36,3 +36,26 @@ counts = [int(c) for c in out if c]
 print(f"dragon x{n * n}: {W}x{H}, {spp} spp, {batch} frames per launch: {W * H * batch} pixels; parked in front of round k:")
 for k, c in enumerate(counts):
     print(f"  round {k + 1}: {c:9d}  ({c / (W * H * batch):.3f} of the pixels{'' if k == 0 else f', {c / counts[k - 1]:.3f} of the round before'})")
+
+# how many of the last round's walks hit the mesh at all (plane 13: tri = ~0 means no hit)
+last = len(counts) - 1
+n = counts[last]
+blocks = (n + 63) // 64
+raw = np.zeros(blocks * 14 * 64 * 4, np.float32)
+rc = tr._L.rt_test_read_wavefront(tr._h, 5 + (last & 1), raw.ctypes.data_as(ctypes.c_void_p), raw.nbytes)
+assert rc == 0, rc
+rec = raw.view(np.uint32).reshape(blocks, 14, 64, 4)
+tri = rec[:, 13, :, 3].reshape(-1)[:n]
+closest = rec[:, 10, :, 0].reshape(-1)[:n].view(np.float32)
+t = rec[:, 13, :, 0].reshape(-1)[:n].view(np.float32)
+hit = tri != 0xffffffff
+print(f"last round: {n} walks, {hit.mean():.3f} of them hit the deferred mesh")
+
+if os.environ.get("PARK_SAMPLE"):   # a sample of the last round's rays for offline analysis (tools/park_probe_model.py)
+    k = min(n, 40000)
+    idx = np.random.RandomState(1).choice(n, k, replace=False)
+    p2 = rec[:, 2, :, :].reshape(-1, 4)[:n][idx].view(np.float32)
+    p3 = rec[:, 3, :, :].reshape(-1, 4)[:n][idx].view(np.float32)
+    np.savez_compressed(os.environ["PARK_SAMPLE"], ro=p2[:, :3], rd=np.concatenate([p2[:, 3:4], p3[:, :2]], axis=1),
+                        hit=hit[idx], t=t[idx])
+    print("sample written:", os.environ["PARK_SAMPLE"])
