@@ -2093,6 +2093,7 @@ static int render_single(rt_handle* h, const rt_params* params, uint32_t rank, u
         const uint64_t need_texels = world == 1 ? (uint64_t)params->width * params->height
                                                 : rt_strip_texels(params->width, params->height, rank, world);
         const bool stream_idle = h->frame_ahead < 0 && hipSetDevice(h->device) == hipSuccess && hipStreamQuery(h->stream) == hipSuccess;
+        (void)hipGetLastError();  // (hipErrorNotReady is an answer, not a failure: not for the launchers' hipGetLastError)
         uint32_t d = ahead_depth(h, params, need_texels, stream_idle);
         if (h->frame_ahead < 0 && d >= 2) {
             // (room for the full depth at once: the batches on the way up would each re-allocate the scratch images -- a
