@@ -104,6 +104,7 @@ struct rt_handle {
     // A call that does not continue the sequence (other parameters, camera, scene, option, strip layout) drops what is left.
     int frame_ahead = -1;                              // -1 automatic (ahead_depth()), 0 off, 2 .. 32 frames
     bool frame_ahead_failed = false;                   // the batch could not be set up once (memory): automatic stays off
+    uint32_t idle_streak = 0;                          // consecutive continuing one-frame calls that found the stream idle
     uint32_t ahead_ramp = 2;                           // automatic: batches of 2, 4, 8, ... frames up to ahead_depth() while the
                                                        // sequence goes on, so that a host that stops after n frames has had
                                                        // at most n rendered in vain; back to 2 when the sequence breaks
@@ -2092,8 +2093,11 @@ static int render_single(rt_handle* h, const rt_params* params, uint32_t rank, u
     if (continues && h->have_scene && world != 0 && rank < world && params->width != 0 && params->height != 0) {
         const uint64_t need_texels = world == 1 ? (uint64_t)params->width * params->height
                                                 : rt_strip_texels(params->width, params->height, rank, world);
-        const bool stream_idle = h->frame_ahead < 0 && hipSetDevice(h->device) == hipSuccess && hipStreamQuery(h->stream) == hipSuccess;
+        // (a host that WAITS for its frames finds the stream idle call after call; one that runs ahead only at its first call)
+        const bool idle_now = h->frame_ahead < 0 && hipSetDevice(h->device) == hipSuccess && hipStreamQuery(h->stream) == hipSuccess;
         (void)hipGetLastError();  // (hipErrorNotReady is an answer, not a failure: not for the launchers' hipGetLastError)
+        h->idle_streak = idle_now ? h->idle_streak + 1u : 0u;
+        const bool stream_idle = h->idle_streak >= 2u;
         uint32_t d = ahead_depth(h, params, need_texels, stream_idle);
         if (h->frame_ahead < 0 && d >= 2) {
             // (room for the full depth at once: the batches on the way up would each re-allocate the scratch images -- a
@@ -2135,7 +2139,10 @@ static int render_single(rt_handle* h, const rt_params* params, uint32_t rank, u
             (void)hipGetLastError();
         }
     }
-    if (!continues) h->ahead_ramp = 2;
+    if (!continues) {
+        h->ahead_ramp = 2;
+        h->idle_streak = 0;
+    }
     const int rc = render_impl(h, params, rank, world);
     if (rc == RT_OK) remember();
     else h->last_single.valid = false;
