@@ -488,6 +488,46 @@ def test_config3_dragon_standin(rt, oracle, tracer, dragon_arrays):
         assert same(tracer.read_image(256, 144), ref), dbg
 
 
+def test_frames_rendered_ahead_on_deferred_walks_and_many_mesh_scenes(rt, tracer, dragon_arrays):
+    """Option frame_ahead with an explicit depth on the scenes the automatic rule leaves alone: the config 3 stand-in
+    with its deferred-walk sequence inside the batch (the sequence's launches, then one blend per call), a many-mesh
+    textured scene, and a strip share with a ragged last strip -- the image after every call equals the
+    one-launch-per-frame run's."""
+    from ray_tracer_2_amd import scenes
+    W, H = 200, 108
+
+    def run(t, rank, world, n=11):
+        out = []
+        t.write_image(np.zeros((H, W, 4), np.float32))
+        for f in range(n):
+            p = rt.make_params(W, H, 3, 2, skybox=1, frames=f)
+            if world == 1:
+                t.render(p)
+                out.append(t.read_image(W, H).copy())
+            else:
+                t.render_strips(p, rank, world)
+                out.append(t.read_texels(t.strip_texels(W, H, rank, world)).copy())
+        return out
+
+    for arrays, rounds in ((dragon_arrays, 2), (rt.SceneArrays.from_scene(scenes.sponza_standin(200)), -1)):
+        tracer.load_scene(arrays)
+        try:
+            tracer.set_option("sort_rounds", rounds)
+            for rank, world in ((0, 1), (1, 3)):
+                tracer.set_option("frame_ahead", 0)
+                want = run(tracer, rank, world)
+                for ahead in (3, 8):
+                    tracer.set_option("frame_ahead", ahead)
+                    tracer.reset_timing()
+                    got = run(tracer, rank, world)
+                    assert tracer.stats().launches < len(got)
+                    for k, (g, w_) in enumerate(zip(got, want)):
+                        assert same(g, w_), (rounds, rank, world, ahead, k)
+        finally:
+            tracer.set_option("sort_rounds", -1)
+            tracer.set_option("frame_ahead", -1)
+
+
 def test_deferred_walks_do_not_change_the_bits(rt, oracle, tracer, dragon_arrays):
     """Option sort_rounds (deferred walks, rt_device.h RenderArgs::park) on the config 3 stand-in: pixels parked in
     front of the big mesh, the mesh walked by rt_walk_kernel, pixels resumed -- image, segment count and the
