@@ -324,6 +324,9 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *   pipeline_when_idle    0 / 1 (0)               1 = also pipeline a frame that finds the handle's stream idle; by default such a
  *                                                 frame -- a host that renders, reads, renders: nothing to overlap with -- takes the
  *                                                 plain in-place launch (no scratch image, no blend kernel)
+ *   primary_per_slot      0 / 1 (1)               a pipelined frame whose camera is not the shared primary table's builds a table
+ *                                                 of its own pipeline slot on its own stream instead of rewriting the shared one
+ *                                                 behind a barrier: the frames of a MOVING camera overlap like those of a standing one
  *   frame_ahead           -1 / 0 / 2..32 (-1)     one-frame calls (rt_render, rt_render_strips, rt_render_multi) that continue an
  *                                                 accumulation (same parameters, camera, scene and options, frames = f, f + 1, ...):
  *                                                 the call for frame f renders frames f .. f + d - 1 in one batched launch and blends

@@ -211,6 +211,17 @@ struct rt_handle {
     rt_camera_uniform primary_camera{};
     uint32_t primary_w = 0, primary_h = 0, primary_rank = 0, primary_world = 0;
     bool primary_with_hits = false;
+    // A pipelined frame whose camera (or shape) is not the shared table's builds a table of its OWN pipeline slot on its own
+    // stream -- ordered behind that slot's previous frame and read by nobody else, so no frame in flight has to finish
+    // first: the frames of a moving camera overlap like those of a standing one (option "primary_per_slot", default 1).
+    struct SlotTable {
+        void* table = nullptr;
+        size_t texels = 0;
+        bool valid = false, with_hits = false;
+        rt_camera_uniform camera{};
+        uint32_t w = 0, h = 0, rank = 0, world = 0;
+    } slot_primary[8];
+    int primary_per_slot = 1;
     int use_primary = 1;  // option "primary_table"
     int primary_hits = 1; // option "primary_hits": the table also holds the primary rays' hits, so that the frames of an
                           // accumulation (still camera, src/core/app.rs:44-53) traverse no primary ray at all
@@ -483,6 +494,7 @@ void rt_destroy(rt_handle* h) {
     free_dev(h->counters);
     free_dev(h->work_counters);
     free_dev(h->primary);
+    for (auto& st : h->slot_primary) free_dev(st.table);
     free_dev(h->pixel_cache_mem);
     free_dev(h->tile_cost[0]);
     free_dev(h->tile_cost[1]);
@@ -1145,6 +1157,7 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->have_scene = true;
         h->history_valid = false;
         h->primary_valid = false;  // (the table holds hits: a function of the scene)
+        for (auto& st : h->slot_primary) st.valid = false;
     } catch (const std::bad_alloc&) {
         return fail(h, RT_ERR_OUT_OF_MEMORY, "out of host memory");
     }
@@ -1213,6 +1226,9 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "primary_hits") {
         h->primary_hits = value ? 1 : 0;
         h->primary_valid = false;
+        for (auto& st : h->slot_primary) st.valid = false;
+    } else if (n == "primary_per_slot") {
+        h->primary_per_slot = value ? 1 : 0;
     } else if (n == "tile_feedback_period") {
         if (value < 1) return fail(h, RT_ERR_INVALID_ARGUMENT, "tile_feedback_period must be >= 1");
         h->tile_feedback_period = value;
@@ -1611,6 +1627,34 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
     a.primary_complete = 0u;
     if (h->use_primary && a.pixel_cache != 0 && params->debug_flag == 0 && params->rays_per_pixel > 0) {
         const size_t texels = (size_t)((params->width + 7) / 8) * ((params->height + 7) / 8) * 64;  // whole 8x8 tiles
+        // (the counter kernels re-intersect every segment, so a launch with counters neither needs nor fills the hits)
+        const bool want_hits = h->primary_hits != 0 && a.count_tests == 0u;
+        const bool shared_fits = h->primary && h->primary_texels >= texels && h->primary_valid && h->primary_w == params->width &&
+                                 h->primary_h == params->height && h->primary_rank == rank && h->primary_world == world &&
+                                 (!want_hits || h->primary_with_hits) &&
+                                 memcmp(&h->primary_camera, &h->camera, sizeof(rt_camera_uniform)) == 0;
+        if (pipe && !shared_fits && h->primary_per_slot != 0 && pslot < 8u) {
+            rt_handle::SlotTable& st = h->slot_primary[pslot];
+            if (st.texels < texels) {
+                HIP_TRY(h, hipStreamSynchronize(S));   // (the slot's previous frame read the old one)
+                free_dev(st.table);
+                st.texels = 0;
+                st.valid = false;
+                HIP_TRY(h, hipMalloc((void**)&st.table, texels * 64));
+                st.texels = texels;
+            }
+            if (!st.valid || st.w != params->width || st.h != params->height || st.rank != rank || st.world != world ||
+                (want_hits && !st.with_hits) || memcmp(&st.camera, &h->camera, sizeof(rt_camera_uniform)) != 0) {
+                a.primary = nullptr;
+                HIP_TRY(h, launch_primary(a, st.table, want_hits, S));
+                st.valid = true;
+                st.w = params->width; st.h = params->height; st.rank = rank; st.world = world;
+                st.with_hits = want_hits;
+                st.camera = h->camera;
+            }
+            a.primary = st.table;
+            a.primary_complete = st.with_hits ? 1u : 0u;
+        } else {
         if (h->primary_texels < texels) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             for (int k = 0; k < rt_handle::PIPE_MAX; ++k)   // (pipelined frames read the table on their own streams)
@@ -1638,6 +1682,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         }
         a.primary = h->primary;
         a.primary_complete = h->primary_with_hits ? 1u : 0u;
+        }
     }
     // a fresh tile counter per launch: a ring of 64, zeroed in one go each time it wraps (launches on
     // one stream are ordered, so every earlier user of the ring is done by then)

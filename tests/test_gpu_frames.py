@@ -630,3 +630,52 @@ def test_snapshot_is_the_frame_of_its_call_while_later_frames_render(rt, cornell
             assert np.array_equal(bits(got[f]), bits(want[f])), (ahead, pipe, f)
         assert np.array_equal(bits(t.read_image(w, h)), bits(want[-1]))
     t.close()
+
+
+def test_moving_camera_frames_overlap_on_slot_tables(rt, oracle, cornell):
+    """Option primary_per_slot: a pipelined frame whose camera is not the shared primary table's builds a table of its own
+    pipeline slot (no barrier), so the frames of a moving camera are in flight together.  Every frame of a camera that
+    moves each call, then stands (accumulation on the slots' tables), then moves back -- taken with rt_snapshot_image
+    while later frames are queued -- equals the run without pipeline and the oracle's."""
+    w, h = 200, 104
+    cam_t = type(cornell.uniform.camera)
+
+    def cam_at(dx):
+        c = cam_t.from_buffer_copy(bytes(cornell.uniform.camera))
+        c.cam_to_world[3][0] += dx
+        return c
+
+    moves = [(0.01 * k, 0) for k in range(1, 9)] + [(0.08, f) for f in range(1, 7)] + [(0.0, 0), (0.0, 1), (0.0, 2)]
+
+    def script(t):
+        out = []
+        t.write_image(np.zeros((h, w, 4), np.float32))
+        for k, (dx, f) in enumerate(moves):
+            t.set_camera(cam_at(dx))
+            t.render(rt.make_params(w, h, 4, 3, skybox=1, frames=f))
+            if k:
+                out.append(t.read_snapshot(w, h))      # the frame before, while this one is queued
+            t.snapshot_image(w, h)
+        out.append(t.read_snapshot(w, h))
+        t.set_camera(cornell.uniform.camera)
+        return out
+
+    t = rt.RayTracer(0, w, h)
+    t.load_scene(cornell)
+    t.set_option("frame_ahead", 0)
+    t.set_option("pipeline", 0)
+    want = script(t)
+    t.set_option("pipeline_when_idle", 1)   # (frames this small finish before the next call: force them through the pipeline)
+    for pipe, per_slot in ((4, 1), (3, 1), (4, 0), (8, 1)):
+        t.set_option("pipeline", pipe)
+        t.set_option("primary_per_slot", per_slot)
+        got = script(t)
+        for k, (g, wnt) in enumerate(zip(got, want)):
+            assert np.array_equal(bits(g), bits(wnt)), (pipe, per_slot, k)
+    t.close()
+    # the oracle on the first moved frame
+    a1 = rt.SceneArrays(cornell.uniform, cornell.spheres, cornell.meshes, cornell.triangles, cornell.nodes)
+    a1.uniform = type(cornell.uniform).from_buffer_copy(bytes(cornell.uniform))
+    a1.uniform.camera.cam_to_world[3][0] += 0.01
+    ref, _ = oracle.render(rt.make_params(w, h, 4, 3, skybox=1, frames=0), a1)
+    assert np.array_equal(bits(want[0]), bits(ref))
