@@ -471,6 +471,26 @@ def main():
             firsts.append((time.perf_counter() - t1) * 1e3)
         tracer.set_camera(cam0)
         extras["ms_first_frame_after_camera_change"] = statistics.median(firsts)
+        # a camera that moves EVERY frame (frames = 0 each call), the host running ahead: each frame builds the primary
+        # table of its own pipeline slot, so the frames overlap (option primary_per_slot; 0 = the shared table behind a barrier)
+        moving = {}
+        for name, per_slot in (("default", 1), ("primary_per_slot_off", 0)):
+            tracer.set_option("primary_per_slot", per_slot)
+            ts = []
+            for rep in range(3):
+                tracer.synchronize()
+                t1 = time.perf_counter()
+                for f in range(48):
+                    cam = cam_t.from_buffer_copy(bytes(cam0))
+                    cam.cam_to_world[3][0] = cam0.cam_to_world[3][0] + 2e-3 * (f + 1 + 48 * rep)
+                    tracer.set_camera(cam)
+                    tracer.render(rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=0))
+                tracer.synchronize()
+                ts.append((time.perf_counter() - t1) / 48 * 1e3)
+            moving[name] = statistics.median(ts)
+        tracer.set_option("primary_per_slot", 1)
+        tracer.set_camera(cam0)
+        extras["ms_per_frame_moving_camera"] = moving
         # independent single frames (every frame a new accumulation, as while the camera moves) pipelined across two
         # handles on the device: each has its own stream and image, so frame k + 1's launch takes the CUs that frame
         # k's draining waves free (the per-frame latency stays ms_per_frame_unoverlapped)
