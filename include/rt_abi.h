@@ -334,8 +334,11 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 bit-identical; a call that does not continue the sequence drops the rest).  -1 =
  *                                                 automatic: only for an LDS-resident scene and a share too small for a launch of its
  *                                                 own to keep the lanes full (batches of about 4 ms: 28 / 14 / 7 frames for a strip
- *                                                 share of 8 / 4 / 2 ranks of config 2, none for the whole frame); 0 = off.  The
- *                                                 counters of rt_get_stats count a batch when it is launched
+ *                                                 share of 8 / 4 / 2 ranks of config 2, none for the whole frame -- except for a host
+ *                                                 that WAITS for every frame, i.e. whose calls find the stream idle twice in a row:
+ *                                                 batches of about 8 ms there, config 2: 7 frames), reached by doubling from 2 so
+ *                                                 that a sequence of n frames renders at most n in vain; 0 = off.  The counters of
+ *                                                 rt_get_stats count a batch when it is launched
  *   cross_prune           0 / 1 (1)               many-mesh kernels: boxes and meshes whose entry distance lies beyond a bound derived
  *                                                 from the closest hit so far (error budget + 12.5 % slack) are not
  *                                                 entered; never in the counter / debug kernels
