@@ -471,10 +471,10 @@ def main():
             firsts.append((time.perf_counter() - t1) * 1e3)
         tracer.set_camera(cam0)
         extras["ms_first_frame_after_camera_change"] = statistics.median(firsts)
-        # a camera that moves EVERY frame (frames = 0 each call), the host running ahead: each frame builds the primary
-        # table of its own pipeline slot, so the frames overlap (option primary_per_slot; 0 = the shared table behind a barrier)
+        # a camera that moves EVERY frame (frames = 0 each call), the host running ahead: a frame whose camera is not the
+        # previous frame's renders without the primary table, so nothing is rebuilt behind a barrier and the frames overlap
         moving = {}
-        for name, per_slot in (("default", 1), ("primary_per_slot_off", 0)):
+        for name, per_slot in (("default", 1),):
             tracer.set_option("primary_per_slot", per_slot)
             ts = []
             for rep in range(3):

@@ -326,7 +326,8 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 plain in-place launch (no scratch image, no blend kernel)
  *   primary_per_slot      0 / 1 (1)               a pipelined frame whose camera is not the shared primary table's builds a table
  *                                                 of its own pipeline slot on its own stream instead of rewriting the shared one
- *                                                 behind a barrier: the frames of a MOVING camera overlap like those of a standing one
+ *                                                 behind a barrier (the frames right after a camera has stopped; while it MOVES --
+ *                                                 the camera differs from the previous frame's -- frames render without a table)
  *   frame_ahead           -1 / 0 / 2..32 (-1)     one-frame calls (rt_render, rt_render_strips, rt_render_multi) that continue an
  *                                                 accumulation (same parameters, camera, scene and options, frames = f, f + 1, ...):
  *                                                 the call for frame f renders frames f .. f + d - 1 in one batched launch and blends

@@ -16,8 +16,9 @@ arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scen
 cam_t = type(arrays.uniform.camera)
 tr = rt.RayTracer(0, W, H)
 tr.load_scene(arrays)
-for per_slot in (0, 1):
-    tr.set_option("primary_per_slot", per_slot)
+for per_slot in (0, 1, 2):
+    tr.set_option("primary_per_slot", per_slot & 1)
+    tr.set_option("primary_table", 0 if per_slot == 2 else 1)   # (2: no table at all -- every pixel computes its own memo)
     res = []
     for rep in range(4):
         tr.synchronize()
@@ -30,5 +31,6 @@ for per_slot in (0, 1):
             tr.render(rt.make_params(W, H, 4, 8, skybox=1, frames=0))
         tr.synchronize()
         res.append((time.perf_counter() - t0) / n * 1e3)
-    print(f"primary_per_slot {per_slot}: {statistics.median(res[1:]):.3f} ms per frame of a moving camera", flush=True)
+    print(f"{'no primary table' if per_slot == 2 else f'primary_per_slot {per_slot}'}: {statistics.median(res[1:]):.3f} ms per frame of a moving camera", flush=True)
+tr.set_option("primary_table", 1)
 tr.set_camera(arrays.uniform.camera)
