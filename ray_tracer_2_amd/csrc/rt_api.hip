@@ -1635,7 +1635,8 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         h->last_frame_camera = h->camera;
         h->last_frame_camera_valid = true;
     }
-    if (h->use_primary && a.pixel_cache != 0 && params->debug_flag == 0 && params->rays_per_pixel > 0 && !camera_moved) {
+    // (a batch keeps the table whatever the camera did: its frames share it)
+    if (h->use_primary && a.pixel_cache != 0 && params->debug_flag == 0 && params->rays_per_pixel > 0 && !(camera_moved && n_batch == 0)) {
         const size_t texels = (size_t)((params->width + 7) / 8) * ((params->height + 7) / 8) * 64;  // whole 8x8 tiles
         // (the counter kernels re-intersect every segment, so a launch with counters neither needs nor fills the hits)
         const bool want_hits = h->primary_hits != 0 && a.count_tests == 0u;
