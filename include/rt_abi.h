@@ -328,7 +328,7 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 of its own pipeline slot on its own stream instead of rewriting the shared one
  *                                                 behind a barrier (the frames right after a camera has stopped; while it MOVES --
  *                                                 the camera differs from the previous frame's -- frames render without a table)
- *   frame_ahead           -1 / 0 / 2..32 (-1)     one-frame calls (rt_render, rt_render_strips, rt_render_multi) that continue an
+ *   frame_ahead           -1 / 0 / 2..64 (-1)     one-frame calls (rt_render, rt_render_strips, rt_render_multi) that continue an
  *                                                 accumulation (same parameters, camera, scene and options, frames = f, f + 1, ...):
  *                                                 the call for frame f renders frames f .. f + d - 1 in one batched launch and blends
  *                                                 frame f; the next d - 1 calls only blend theirs (the image after every call is
@@ -343,7 +343,7 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *   cross_prune           0 / 1 (1)               many-mesh kernels: boxes and meshes whose entry distance lies beyond a bound derived
  *                                                 from the closest hit so far (error budget + 12.5 % slack) are not
  *                                                 entered; never in the counter / debug kernels
- *   batch_frames          1..32 (16)              frames per launch of rt_render_frames
+ *   batch_frames          1..64 (16)              frames per launch of rt_render_frames
  *   batch_tile_major      0 / 1 (1)               a batch's work items in (tile, frame) order instead of (frame, tile)
  *   forest                0 / 1 (1)  (upload)     BVH meshes of one local space walked per lane back to back
  *   flat2                 0 / 1 (1)  (upload)     meshes whose BVH is a root with two leaves run as straight-line code

@@ -1289,7 +1289,7 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         h->pipeline_when_idle = value ? 1 : 0;
     } else if (n == "frame_ahead") {
         if (value < -1 || value == 1 || value > (int)RT_MAX_BATCH_FRAMES)
-            return fail(h, RT_ERR_INVALID_ARGUMENT, "frame_ahead must be -1 (automatic), 0 (off) or 2 .. 32 (frames per batch)");
+            return fail(h, RT_ERR_INVALID_ARGUMENT, "frame_ahead must be -1 (automatic), 0 (off) or 2 .. 64 (frames per batch)");
         h->frame_ahead = value;
         h->frame_ahead_failed = false;
     } else if (n == "fast_miss") {
@@ -1309,7 +1309,7 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
     } else if (n == "batch_tile_major") {
         h->batch_tile_major = value ? 1 : 0;
     } else if (n == "batch_frames") {
-        if (value < 1 || value > (int)RT_MAX_BATCH_FRAMES) return fail(h, RT_ERR_INVALID_ARGUMENT, "batch_frames must be 1..32");
+        if (value < 1 || value > (int)RT_MAX_BATCH_FRAMES) return fail(h, RT_ERR_INVALID_ARGUMENT, "batch_frames must be 1..64");
         h->batch_frames_opt = value;
     } else {
         return fail(h, RT_ERR_INVALID_ARGUMENT, "unknown option " + n);

@@ -275,7 +275,7 @@ constexpr uint32_t WF_STATE_PLANES = 6, WF_HIT_PLANES = 2;
 // no hit), written by rt_walk_kernel.  A park writes 9 planes (144 B) and a resume reads 11 (176 B) in the usual case.
 constexpr uint32_t PARK_PLANES = 14;
 
-constexpr uint32_t RT_MAX_BATCH_FRAMES = 32;
+constexpr uint32_t RT_MAX_BATCH_FRAMES = 64;  // (config 3 stand-in: 5.24 ms per frame at 32 per launch, 5.09 at 64; config 2: 1.126 / 1.119)
 // rt_blend_frames_kernel: image = the accumulation image, scratch = batch frame 0
 struct BlendArgs {
     float4* image;

@@ -28,7 +28,7 @@ def sponza(rt):
     return rt.SceneArrays.from_scene(scenes.sponza_standin(200))
 
 
-@pytest.mark.parametrize("f0,n,batch", [(0, 8, 16), (0, 2, 16), (3, 20, 16), (1, 8, 3), (-1, 5, 16), (0, 33, 32), (5, 1, 16)])
+@pytest.mark.parametrize("f0,n,batch", [(0, 8, 16), (0, 2, 16), (3, 20, 16), (1, 8, 3), (-1, 5, 16), (0, 33, 32), (2, 70, 64), (5, 1, 16)])
 def test_render_frames_equals_sequential_frames(rt, tracer, cornell, f0, n, batch):
     w, h = 200, 100
     tracer.load_scene(cornell)
@@ -553,7 +553,7 @@ def test_frames_rendered_ahead_leave_the_same_image_after_every_call(rt, oracle,
     try:
         tracer.set_option("frame_ahead", 0)
         want = script(tracer)
-        for ahead in (-1, 2, 5, 32):
+        for ahead in (-1, 2, 5, 32, 64):
             tracer.set_option("frame_ahead", ahead)
             tracer.reset_timing()
             got = script(tracer)
