@@ -201,7 +201,7 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU-staged rehearsal on one GPU)")
-    ap.add_argument("--batch", type=int, default=32, help="frames per launch of rt_render_frames (1..32; 1 = one launch per frame)")
+    ap.add_argument("--batch", type=int, default=64, help="frames per launch of rt_render_frames (1..64; 1 = one launch per frame)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic in this run (two short child runs under rocprofv3 --pmc); use the committed profile")
     ap.add_argument("--variant", type=int, default=None, help="kernel variant (tuning; default: library default)")
@@ -261,7 +261,7 @@ def main():
     arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
     tracer = rt.RayTracer(device=device, max_width=W, max_height=H)
     tracer.load_scene(arrays)
-    tracer.set_option("batch_frames", max(1, min(32, args.batch)))
+    tracer.set_option("batch_frames", max(1, min(64, args.batch)))
     if args.variant is not None:
         tracer.set_option("kernel_variant", args.variant)
     if args.blocks is not None:
