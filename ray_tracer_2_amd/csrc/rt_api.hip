@@ -1371,18 +1371,28 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         if (n_batch > RT_MAX_BATCH_FRAMES) return fail(h, RT_ERR_INVALID_ARGUMENT, "batch too large");
         const uint64_t scratch_stride = need_texels;
         if (h->batch_scratch_texels < scratch_stride * n_batch) {
+            // Room for the largest batch the options allow, not just this one: a later, larger batch of the same shape
+            // (a warm-up of 5 frames, then 20) must not re-allocate -- a hipMalloc of hundreds of megabytes costs tens of
+            // milliseconds -- in the middle of a host's frame sequence.
+            const uint64_t slots = std::max<uint64_t>(n_batch, std::min<uint64_t>((uint64_t)h->batch_frames_opt, RT_MAX_BATCH_FRAMES));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             free_dev(h->batch_scratch);
             h->batch_scratch_texels = 0;
-            HIP_TRY(h, hipMalloc((void**)&h->batch_scratch, scratch_stride * n_batch * sizeof(float4)));
-            h->batch_scratch_texels = scratch_stride * n_batch;
+            if (hipMalloc((void**)&h->batch_scratch, scratch_stride * slots * sizeof(float4)) == hipSuccess) {
+                h->batch_scratch_texels = scratch_stride * slots;
+            } else {   // (not that much memory: what this batch needs)
+                (void)hipGetLastError();
+                HIP_TRY(h, hipMalloc((void**)&h->batch_scratch, scratch_stride * n_batch * sizeof(float4)));
+                h->batch_scratch_texels = scratch_stride * n_batch;
+            }
             h->scratch_w = 0;  // (new memory: zero it below)
         }
         // The padding rows of a ragged last strip are never rendered: they must blend as zeros, not as the samples an
-        // earlier batch of another shape left there.  Zero the scratch whenever the layout of the batch changes.
+        // earlier batch of another shape left there.  Zero ALL of the scratch whenever the shape of its frames changes
+        // (slot k of any later batch of this shape starts at k strides: the number of frames does not matter).
         if (h->scratch_w != params->width || h->scratch_h != params->height || h->scratch_rank != rank ||
-            h->scratch_world != world || h->scratch_n != n_batch) {
-            HIP_TRY(h, hipMemsetAsync(h->batch_scratch, 0, scratch_stride * n_batch * sizeof(float4), h->stream));
+            h->scratch_world != world) {
+            HIP_TRY(h, hipMemsetAsync(h->batch_scratch, 0, h->batch_scratch_texels * sizeof(float4), h->stream));
             h->scratch_w = params->width; h->scratch_h = params->height; h->scratch_rank = rank;
             h->scratch_world = world; h->scratch_n = n_batch;
         }
