@@ -217,7 +217,7 @@ int rt_render(rt_handle* h, const rt_params* params);
 /* n_frames consecutive frames of RayTracer::render with Params.frames advancing by one per frame, as
  * App::update does while accumulating (app.rs:44-53, 160-162): the image afterwards is bit-identical to
  * n_frames calls of rt_render with frames, frames + 1, ...  The only dependency between frames is the
- * per-texel blend (wgsl:154-161), so the frames of a batch (option "batch_frames", default 16, at most
+ * per-texel blend (wgsl:154-161), so the frames of a batch (option "batch_frames", default 32, at most
  * 32) are sampled by ONE persistent launch over (frame, tile) work items -- the waves never drain
  * between frames -- into scratch images, and a dense second kernel blends them in frame order with
  * the shader's two operations.  Intermediate frames of a batch are not observable. */
@@ -343,7 +343,7 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *   cross_prune           0 / 1 (1)               many-mesh kernels: boxes and meshes whose entry distance lies beyond a bound derived
  *                                                 from the closest hit so far (error budget + 12.5 % slack) are not
  *                                                 entered; never in the counter / debug kernels
- *   batch_frames          1..64 (16)              frames per launch of rt_render_frames
+ *   batch_frames          1..64 (32)              frames per launch of rt_render_frames
  *   batch_tile_major      0 / 1 (1)               a batch's work items in (tile, frame) order instead of (frame, tile)
  *   forest                0 / 1 (1)  (upload)     BVH meshes of one local space walked per lane back to back
  *   flat2                 0 / 1 (1)  (upload)     meshes whose BVH is a root with two leaves run as straight-line code

@@ -154,7 +154,7 @@ struct rt_handle {
     size_t park_capacity = 0;  // records per queue
     uint32_t* park_counts = nullptr;
     int batch_tile_major = 1;  // option "batch_tile_major": (tile, frame) instead of (frame, tile) order of a batch's work items
-    int batch_frames_opt = 16;  // option "batch_frames": frames per launch of rt_render_frames (1..RT_MAX_BATCH_FRAMES)
+    int batch_frames_opt = 32;  // option "batch_frames": frames per launch of rt_render_frames (1..RT_MAX_BATCH_FRAMES)
     // rt_render_multi: what the root's stream has to finish before this handle's image may be overwritten
     // (owned by THIS handle, created on the root's device -- an event is recorded on a stream of its own device --,
     // so that destroying the root first leaves nothing dangling)

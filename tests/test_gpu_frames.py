@@ -42,7 +42,7 @@ def test_render_frames_equals_sequential_frames(rt, tracer, cornell, f0, n, batc
         got = tracer.read_image(w, h)
         st = tracer.stats()
     finally:
-        tracer.set_option("batch_frames", 16)
+        tracer.set_option("batch_frames", 32)
     assert np.array_equal(bits(got), bits(want))
     assert st.frames == n and st.launches == -(-n // batch) and st.paths == w * h * 4 * n   # equal batches
 
@@ -111,7 +111,7 @@ def test_segments_reused_is_exact(rt, tracer, cornell, variant, lds, batch):
     finally:
         tracer.set_option("kernel_variant", -1)
         tracer.set_option("lds_scene", 1)
-        tracer.set_option("batch_frames", 16)
+        tracer.set_option("batch_frames", 32)
         tracer.set_option("primary_hits", 1)
         tracer.set_option("frame_ahead", -1)
     s, s0 = got[1][0], got[0][0]
@@ -184,7 +184,7 @@ def test_render_frames_under_every_kernel_option(rt, tracer, cornell, kw):
         got = tracer.read_image(w, h)
     finally:
         tracer.set_option(k, {"lds_scene": 1, "pixel_cache": 1, "tile_feedback": 1, "batch_tile_major": 1}[k])
-        tracer.set_option("batch_frames", 16)
+        tracer.set_option("batch_frames", 32)
     assert np.array_equal(bits(got), bits(want))
 
 

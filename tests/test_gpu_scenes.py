@@ -619,7 +619,7 @@ def test_deferred_walks_do_not_change_the_bits(rt, oracle, tracer, dragon_arrays
         tracer.set_counters(False)
         tracer.set_option("sort_rounds", -1)
         tracer.set_option("hybrid", 0)
-        tracer.set_option("batch_frames", 16)
+        tracer.set_option("batch_frames", 32)
 
 
 def deep_chain_scene(rt, cornell, levels=36, trap=31):

@@ -39,7 +39,7 @@ for mode, batch, pipe in (("one launch per frame, no pipeline", 1, 0), ("one lau
             base[mode] = t
         print(f"{mode:48s} world {world}: {t:.3f} ms per frame for rank 0's share -> compute-only speed-up {base[mode] / t:.2f}x", flush=True)
 # one CALL per frame (the reference's mode: app.rs:44-53 advances Params.frames, one render per redraw)
-tr.set_option("batch_frames", 16)
+tr.set_option("batch_frames", 32)
 tr.set_option("pipeline", -1)
 N = 256
 for mode, ahead in (("one call per frame, frame_ahead off", 0), ("one call per frame, default options", -1)):
