@@ -218,7 +218,7 @@ int rt_render(rt_handle* h, const rt_params* params);
  * App::update does while accumulating (app.rs:44-53, 160-162): the image afterwards is bit-identical to
  * n_frames calls of rt_render with frames, frames + 1, ...  The only dependency between frames is the
  * per-texel blend (wgsl:154-161), so the frames of a batch (option "batch_frames", default 32, at most
- * 32) are sampled by ONE persistent launch over (frame, tile) work items -- the waves never drain
+ * 64) are sampled by ONE persistent launch over (frame, tile) work items -- the waves never drain
  * between frames -- into scratch images, and a dense second kernel blends them in frame order with
  * the shader's two operations.  Intermediate frames of a batch are not observable. */
 int rt_render_frames(rt_handle* h, const rt_params* params, uint32_t n_frames);
