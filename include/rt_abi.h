@@ -354,7 +354,7 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *   sort_rounds           -1 / 0 / 1..64 (-1)     deferred walks (one big mesh among a few): park pixels in front of the
  *                                                 mesh, walk it for all parked rays in a kernel of its own, resume --
  *                                                 for that many rounds; -1: by the work of the launch and the mesh's size,
- *                                                 and only while both park queues fit a quarter of the free memory
+ *                                                 and only while both park queues fit half of the free memory
  *   defer_min_nodes       >= 1 (1024) (upload)    smallest BVH (internal nodes) whose mesh may be the deferred one
  *   fast_miss             0 / 1 (1)               a memoised primary ray that leaves the scene ends its pixel in one step: the
  *                                                 remaining samples are that segment again and their light is added in order

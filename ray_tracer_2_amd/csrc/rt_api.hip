@@ -1527,7 +1527,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             n_rounds = units >= 24.0 ? 6u : units >= 12.0 ? 4u : units >= 8.0 ? 3u : 0u;
         if (n_rounds && h->park_capacity < park_records) {
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || 2 * park_bytes > free_b / 4) n_rounds = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || 2 * park_bytes > free_b / 2) n_rounds = 0;  // (both queues within half of what is free: 288 GB are there to be used)
         }
     }
     bool rounds = n_rounds > 0 && h->have_defer && a.many_mesh == 0 && a.kernel_variant == 0 && params->debug_flag == 0 &&
