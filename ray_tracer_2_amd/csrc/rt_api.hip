@@ -1522,7 +1522,10 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         // (tuned on the config 3 and config 5 stand-ins: the longer the walks -- the bigger the mesh's BVH --, the
         // earlier a round pays for its fixed cost)
         if (h->defer_internal >= 400000u)
-            n_rounds = units >= 48.0 ? 12u : units >= 24.0 ? 8u : units >= 12.0 ? 4u : units >= 4.0 ? 3u : units >= 2.0 ? 2u : 0u;
+            // (config 5 stand-in at 3840 x 2160, 64 spp, 16 frames per launch = 256 units: 102.9 / 98.4 / 96.8 / 96.8 / 97.3 ms
+            // per frame with 8 / 12 / 16 / 24 / 32 rounds)
+            // (32 frames per launch = 512 units: 95.6 ms with 16 rounds, 95.0 with 24)
+            n_rounds = units >= 384.0 ? 24u : units >= 96.0 ? 16u : units >= 48.0 ? 12u : units >= 24.0 ? 8u : units >= 12.0 ? 4u : units >= 4.0 ? 3u : units >= 2.0 ? 2u : 0u;
         else
             n_rounds = units >= 24.0 ? 6u : units >= 12.0 ? 4u : units >= 8.0 ? 3u : 0u;
         if (n_rounds && h->park_capacity < park_records) {
