@@ -338,7 +338,9 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 share of 8 / 4 / 2 ranks of config 2, none for the whole frame -- except for a host
  *                                                 that WAITS for every frame, i.e. whose calls find the stream idle twice in a row:
  *                                                 batches of about 8 ms there, config 2: 7 frames), reached by doubling from 2 so
- *                                                 that a sequence of n frames renders at most n in vain; 0 = off.  The counters of
+ *                                                 that a sequence of n frames renders at most n in vain; for a scene read from
+ *                                                 global memory (many meshes, a big mesh) up to 8 frames and about 33 ms by a work
+ *                                                 estimate, nothing for frames of 8 ms and more; 0 = off.  The counters of
  *                                                 rt_get_stats count a batch when it is launched
  *   cross_prune           0 / 1 (1)               many-mesh kernels: boxes and meshes whose entry distance lies beyond a bound derived
  *                                                 from the closest hit so far (error budget + 12.5 % slack) are not

@@ -2094,9 +2094,20 @@ static bool same_frame_params(const rt_params& a, const rt_params& b, int32_t b_
 static uint32_t ahead_depth(const rt_handle* h, const rt_params* params, uint64_t need_texels, bool stream_idle) {
     if (params->debug_flag != 0 || params->rays_per_pixel <= 0 || h->count_tests != 0 || params->frames < 1) return 0;
     if (h->frame_ahead >= 0) return h->frame_ahead >= 2 ? std::min<uint32_t>((uint32_t)h->frame_ahead, RT_MAX_BATCH_FRAMES) : 0u;
-    if (h->frame_ahead_failed || !h->lds_scene || h->force_global) return 0;
+    if (h->frame_ahead_failed) return 0;
     const double segments = (double)need_texels * (double)params->rays_per_pixel *
                             (double)((params->number_of_bounces < 0 ? 0 : params->number_of_bounces) + 1);
+    if (!h->lds_scene || h->force_global) {
+        // Scenes read from global memory (many meshes, a big mesh): their rays cost about five times an LDS-resident
+        // scene's, a launch per frame leaves more undone (the deferred walks of a big mesh need batches at all), and what a
+        // batch returns is larger -- config 5's geometry 4.43 -> 3.40 ms per call at 8 frames, the 200-mesh stand-in 3.50 ->
+        // 3.16, the sponza-sized one 5.95 -> 5.65 -- so the bound is looser: about two display refreshes (33 ms) by this
+        // estimate, at most 8 frames, and nothing for frames that fill such a batch by themselves.
+        const double ms_est = segments / (1920.0 * 1080.0 * 8.0 * 5.0) * 1.13 * 5.0;
+        const double dn = 33.0 / (ms_est > 1e-3 ? ms_est : 1e-3);
+        const uint32_t nn = dn >= 8.0 ? 8u : (uint32_t)dn;
+        return nn >= 4u ? nn : 0u;
+    }
     const double ms = segments / (1920.0 * 1080.0 * 8.0 * 5.0) * 1.13;
     // (a host that waits for every frame gives the GPU nothing else to do: batches of about 8 ms there)
     const double d = (stream_idle ? 8.0 : 4.0) / (ms > 1e-3 ? ms : 1e-3);
