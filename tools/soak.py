@@ -15,7 +15,11 @@ import ray_tracer_2_amd as rt  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 W, H = 320, 180
-arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
+if len(sys.argv) > 2 and sys.argv[2] == "many":   # a many-mesh textured scene, read from global memory
+    from ray_tracer_2_amd import scenes
+    arrays = rt.SceneArrays.from_scene(scenes.sponza_standin(200))
+else:
+    arrays = rt.SceneArrays.load(os.path.join(ROOT, "tests", "golden", "cornell_scene.npz"))
 cam_t = type(arrays.uniform.camera)
 
 
