@@ -57,5 +57,5 @@ if os.environ.get("PARK_SAMPLE"):   # a sample of the last round's rays for offl
     p2 = rec[:, 2, :, :].reshape(-1, 4)[:n][idx].view(np.float32)
     p3 = rec[:, 3, :, :].reshape(-1, 4)[:n][idx].view(np.float32)
     np.savez_compressed(os.environ["PARK_SAMPLE"], ro=p2[:, :3], rd=np.concatenate([p2[:, 3:4], p3[:, :2]], axis=1),
-                        hit=hit[idx], t=t[idx])
+                        hit=hit[idx], t=t[idx], closest=closest[idx])
     print("sample written:", os.environ["PARK_SAMPLE"])

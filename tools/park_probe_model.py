@@ -72,3 +72,23 @@ for B in (3, 4, 6, 8, 12, 16, 24, 32):
     saved = (vm <= B).sum()
     cost = np.minimum(vm, B).sum() + np.minimum(vh, B).sum()
     print(f"budget {B:2d} visits: {saved / K:.3f} of the parks avoided; {cost / K:.1f} inline visits per probed ray")
+
+# how many parks a cut of the root box against the closest hit so far would spare (the small meshes come first in the item
+# order): the ray enters the deferred mesh's root box beyond that hit.  World distance = local distance here (the stand-in's
+# dragon has a similarity transform of scale s: t_world = t_local * s).
+if "closest" in sample.files:
+    root = nd[0]
+    c0 = np.array(m["model_to_world"], np.float64)[0, :3]
+    scale = float(np.sqrt(np.dot(c0, c0)))
+    beyond = 0
+    for i in range(K):
+        lo = w2m[0, :3] * ro[i, 0] + w2m[1, :3] * ro[i, 1] + w2m[2, :3] * ro[i, 2] + w2m[3, :3]
+        ld = w2m[0, :3] * rd[i, 0] + w2m[1, :3] * rd[i, 1] + w2m[2, :3] * rd[i, 2]
+        ld = ld / np.sqrt(np.dot(ld, ld))
+        with np.errstate(divide="ignore"):
+            inv = 1.0 / ld
+        entry = box(lo, inv, root["aabb_min"].astype(np.float64), root["aabb_max"].astype(np.float64))
+        if entry < INF and entry * scale * 1.0 > float(sample["closest"][i]) * 1.125:
+            beyond += 1
+    print(f"root box entered beyond 1.125 x the closest hit so far: {beyond / K:.3f} of the parked rays "
+          f"(closest known at park time: {np.isfinite(sample['closest'][:K]).mean():.3f} finite, median {np.median(sample['closest'][:K]):.3g})")
