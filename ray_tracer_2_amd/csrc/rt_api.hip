@@ -225,7 +225,7 @@ struct rt_handle {
         bool valid = false, with_hits = false;
         rt_camera_uniform camera{};
         uint32_t w = 0, h = 0, rank = 0, world = 0;
-    } slot_primary[8];
+    } slot_primary[PIPE_MAX];
     int primary_per_slot = 1;
     // A frame whose camera is not the previous frame's (the camera is MOVING) renders without a table: every pixel computes its
     // own memo (its primary ray is traversed once, by its first sample) -- building a table that the next frame throws away
@@ -1665,7 +1665,7 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
                                  h->primary_h == params->height && h->primary_rank == rank && h->primary_world == world &&
                                  (!want_hits || h->primary_with_hits) &&
                                  memcmp(&h->primary_camera, &h->camera, sizeof(rt_camera_uniform)) == 0;
-        if (pipe && !shared_fits && h->primary_per_slot != 0 && pslot < 8u) {
+        if (pipe && !shared_fits && h->primary_per_slot != 0 && pslot < (uint32_t)rt_handle::PIPE_MAX) {
             rt_handle::SlotTable& st = h->slot_primary[pslot];
             if (st.texels < texels) {
                 HIP_TRY(h, hipStreamSynchronize(S));   // (the slot's previous frame read the old one)
