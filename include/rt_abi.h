@@ -412,6 +412,10 @@ int rt_test_read_wavefront(rt_handle* h, int which, void* out, uint64_t bytes);
  * buffers and without any HIP call (runs without a GPU): checks that a failure inside the group still closes the group
  * and aborts the communicators.  Error text: rt_last_error(NULL). */
 int rt_test_rccl_gather(const char* lib_path, int n_ranks);
+/* The automatic depth of option "frame_ahead" for a one-frame call that continues an accumulation (no GPU needed): the
+ * scene staged in LDS (1) or read from global memory (0), the texels of the call's share, samples per pixel, bounces,
+ * and whether the host counts as one that waits for every frame.  0 = the call renders its own frame only. */
+int rt_test_frame_ahead_depth(int lds_scene, uint64_t texels, int rays_per_pixel, int number_of_bounces, int host_waits);
 
 const char* rt_last_error(rt_handle* h);
 void rt_destroy(rt_handle* h);

@@ -2712,6 +2712,20 @@ int rt_test_read_wavefront(rt_handle* h, int which, void* out, uint64_t bytes) {
     return RT_OK;
 }
 
+// Test-only, no GPU needed: the automatic depth of option "frame_ahead" (ahead_depth) for a one-frame call that continues an
+// accumulation -- scene staged in LDS or read from global memory, texels of the call's share, samples per pixel, bounces,
+// and whether the host counts as one that waits for its frames.  tests/test_frame_ahead_policy.py pins the documented
+// figures with it.
+int rt_test_frame_ahead_depth(int lds_scene, uint64_t texels, int rays_per_pixel, int number_of_bounces, int host_waits) {
+    rt_handle h;
+    h.lds_scene = lds_scene != 0;
+    rt_params p{};
+    p.rays_per_pixel = rays_per_pixel;
+    p.number_of_bounces = number_of_bounces;
+    p.frames = 1;
+    return (int)ahead_depth(&h, &p, texels, host_waits != 0);
+}
+
 // Test-only: the grouped gather of rt_render_multi against the RCCL-shaped library at `lib_path`, on fake buffers and
 // with no HIP call (so that it runs on a machine without a GPU): n_ranks communicators from ncclCommInitAll, one
 // rccl_grouped_gather over them; on failure the communicators are aborted, as render_multi_impl does.  The error text

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("RT2_LIB") or os.path.join(_HERE, "librt2_mi355x.so")
 # every symbol include/rt_abi.h declares
 EXPORTS = [
     "rt_create", "rt_upload_scene", "rt_upload_textures", "rt_set_camera", "rt_render",
-    "rt_render_strips", "rt_render_multi", "rt_render_frames", "rt_render_strips_frames", "rt_render_multi_frames", "rt_read_multi_frame", "rt_test_device_units", "rt_test_sweep", "rt_test_device_sample_texture", "rt_test_read_wavefront", "rt_test_rccl_gather", "rt_strip_texels", "rt_assemble_strips", "rt_read_image", "rt_write_image", "rt_snapshot_image", "rt_read_snapshot",
+    "rt_render_strips", "rt_render_multi", "rt_render_frames", "rt_render_strips_frames", "rt_render_multi_frames", "rt_read_multi_frame", "rt_test_device_units", "rt_test_sweep", "rt_test_device_sample_texture", "rt_test_read_wavefront", "rt_test_rccl_gather", "rt_test_frame_ahead_depth", "rt_strip_texels", "rt_assemble_strips", "rt_read_image", "rt_write_image", "rt_snapshot_image", "rt_read_snapshot",
     "rt_synchronize", "rt_get_stats", "rt_last_launch", "rt_reset_timing", "rt_bind_image", "rt_set_stream", "rt_set_option", "rt_set_counters", "rt_device_image", "rt_stream",
     "rt_last_error", "rt_destroy", "rt_version", "rt_device_count", "rt_abi_sizes",
     "rt_scene_load_builtin", "rt_scene_create", "rt_scene_set_camera", "rt_transform_cam",
@@ -67,6 +67,7 @@ def load():
         "rt_assemble_strips": (i32, [vp, vp, u32, u32, u32]),
         "rt_read_image": (i32, [vp, vp, C.c_size_t]),
         "rt_write_image": (i32, [vp, vp, C.c_size_t]),
+        "rt_test_frame_ahead_depth": (i32, [i32, u64, i32, i32, i32]),
         "rt_snapshot_image": (i32, [vp, C.c_size_t]),
         "rt_read_snapshot": (i32, [vp, vp, C.c_size_t]),
         "rt_synchronize": (i32, [vp]),
