@@ -307,6 +307,9 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *   primary_hits          0 / 1 (1)               the primary table also holds every pixel's primary HIT (once per camera, frame
  *                                                 size, strip layout and scene): while the camera stands still no primary ray is
  *                                                 traversed at all; 0: a pixel's first sample of every frame traverses it again
+ *   memo_in_table         0 / 1 (1)               kernels whose memo has no room in LDS read it in place from a complete primary
+ *                                                 table instead of copying it into a buffer in global memory (round 5: that copy
+ *                                                 was 96 % of what those kernels wrote to memory); 0: the copy
  *   vote_eighths          -1 / 0..8 (-1)          intersection vote: traverse when wanting lanes x 8 >= lanes x this
  *   vote_patience         -1 / >= 0 (-1)          ... or when some lane has waited this many iterations; -1: by the kind of
  *                                                 launch (6 and 3 for a scene in LDS on the few-mesh kernels, 7 and 16 for

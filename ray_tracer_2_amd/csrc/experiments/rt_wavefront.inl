@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 4) rt_wf_shade_kernel(const Ren
                 hit.hit = false;
                 hit.suspended = false;
                 if (mode == STEP_REUSE) {
-                    memo_hit_load<true>(a, memo, hit);
+                    memo_hit_load<true>(a, s, memo, hit);
                     n_reused += 1;
                 }
                 done = path_end<false, false>(a, s, nullptr, mode, hit, n_segments);

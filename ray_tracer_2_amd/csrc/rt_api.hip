@@ -235,6 +235,8 @@ struct rt_handle {
     int use_primary = 1;  // option "primary_table"
     int primary_hits = 1; // option "primary_hits": the table also holds the primary rays' hits, so that the frames of an
                           // accumulation (still camera, src/core/app.rs:44-53) traverse no primary ray at all
+    int memo_in_table = 1; // option "memo_in_table": kernels whose memo has no room in LDS read it straight from a complete
+                          // primary table (RenderArgs::pixel_cache == 4) instead of copying it into a global-memory buffer
     int tile_feedback = 1;
     int tile_feedback_period = 8;  // frames an order is kept before it is refreshed
     bool have_order = false, costs_ready = false;
@@ -1239,6 +1241,8 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
         h->primary_hits = value ? 1 : 0;
         h->primary_valid = false;
         for (auto& st : h->slot_primary) st.valid = false;
+    } else if (n == "memo_in_table") {
+        h->memo_in_table = value ? 1 : 0;
     } else if (n == "primary_per_slot") {
         h->primary_per_slot = value ? 1 : 0;
     } else if (n == "tile_feedback_period") {
@@ -1622,16 +1626,6 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         // stream idle before it, so everything older is complete; this frame's samples go to a scratch image, and its blend
         // follows that launch in the handle's stream's order anyway -- so the second frame of a burst overlaps the first)
         if (h->pipe_main_set && h->pipe_main_need) HIP_TRY(h, hipStreamWaitEvent(S, h->pipe_main, 0));
-        if (a.pixel_cache == 2u && pslot != 0u) {   // the global-memory memo is per resident wave: one per concurrent launch
-            const size_t need = (size_t)h->persistent_blocks * WAVES_PER_BLOCK * PIXEL_MEMO_DWORDS * 64u;
-            if (h->pipe_memo_words[pslot] < need) {
-                HIP_TRY(h, hipStreamSynchronize(h->stream));
-                free_dev(h->pipe_memo[pslot]);
-                HIP_TRY(h, hipMalloc((void**)&h->pipe_memo[pslot], need * sizeof(uint32_t)));
-                h->pipe_memo_words[pslot] = need;
-            }
-            a.pixel_cache_mem = h->pipe_memo[pslot];
-        }
     }
     auto barrier_other = [&]() -> hipError_t {   // before rewriting a shared table: the other stream's sampling launch is done
         wrote_tables = true;
@@ -1715,6 +1709,26 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         a.primary = h->primary;
         a.primary_complete = h->primary_with_hits ? 1u : 0u;
         }
+    }
+    // With a complete table a lane's memo EQUALS its table entry for the pixel's whole life: the kernels whose memo has no
+    // room in LDS read the entry in place (pixel_cache = 4) instead of copying it into a buffer in global memory --
+    // that copy was most of what the global-memory kernels wrote and half of what they read.
+    if (a.pixel_cache == 2u && a.lds_scene == 0u && a.primary != nullptr && a.primary_complete != 0u && h->memo_in_table != 0) {
+        a.pixel_cache = 4u;
+        a.pixel_cache_mem = nullptr;
+    }
+    // The global-memory memo is per resident wave and stateful across a pixel's samples: one per concurrent launch.
+    // Slot 0 has its own too -- a plain launch on the handle's stream (pixel_cache_mem) may still be running beside
+    // the pipelined frame of slot 0 when pipe_main_need is false (a frame that found the stream idle).
+    if (pipe && a.pixel_cache == 2u) {
+        const size_t need = (size_t)h->persistent_blocks * WAVES_PER_BLOCK * PIXEL_MEMO_DWORDS * 64u;
+        if (h->pipe_memo_words[pslot] < need) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            free_dev(h->pipe_memo[pslot]);
+            HIP_TRY(h, hipMalloc((void**)&h->pipe_memo[pslot], need * sizeof(uint32_t)));
+            h->pipe_memo_words[pslot] = need;
+        }
+        a.pixel_cache_mem = h->pipe_memo[pslot];
     }
     // a fresh tile counter per launch: a ring of 64, zeroed in one go each time it wraps (launches on
     // one stream are ordered, so every earlier user of the ring is done by then)

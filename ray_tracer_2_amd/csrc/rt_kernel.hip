@@ -1511,6 +1511,33 @@ DEV size_t primary_index(uint32_t width, uint32_t x, uint32_t y) {
     return ((size_t)(y >> 3) * tiles_x + (x >> 3)) * 64u + (((y & 7u) << 3) | (x & 7u));
 }
 
+// pixel_cache == 4 (round 5): the lane's memo IS its entry of the primary table.  With a complete table
+// (RenderArgs::primary_complete) a pixel's memo equals its table entry for the pixel's whole life -- nothing ever rewrites
+// it (memo_hit_store would store the same bits) --, so the kernels whose memo does not fit the LDS read the 13 dwords
+// straight from the read-only table at every sample instead of copying them into a per-wave buffer in global memory
+// first: that copy was written one dword per 32-byte sector (the buffer is lane-interleaved and lanes take pixels a few
+// at a time) and did not survive in the L2 between a pixel's samples either -- 740 of the 774 MB the sponza-sized stand-in
+// wrote per frame and 1.4 of its 2.5 GB of reads.  Same values, same operations on them.
+struct TableMemo {
+    typedef const __attribute__((address_space(1))) uint32_t* P;
+    P p;
+    DEV uint32_t operator[](uint32_t i) const { return p[i >> 6]; }  // (the callers index the lane-interleaved layout: k * 64)
+};
+// read-only access to the memo of the pixel `s` holds: the table entry (pixel_cache == 4) or with_memo's buffer
+// (TABLE: compiled into the kernels that read the scene from global memory only -- the LDS-scene kernels keep their memo
+// in LDS, and the extra branch cost the headline instantiation 8 B of scratch per lane)
+template <bool WF = false, bool TABLE = true, class F>
+DEV void with_memo_ro(const RenderArgs& a, uint32_t* ls, const PixelState& s, F&& f) {
+    if constexpr (!WF && TABLE) {
+        if (a.pixel_cache == 4u) {  // wave-uniform
+            ColdArgs& ca = cold_args();
+            f(TableMemo{(TableMemo::P)a.primary + primary_index(ca.params.width, s.x, frame_row_of(ca, s.out_row)) * 16u});
+            return;
+        }
+    }
+    with_memo<WF>(a, ls, f);
+}
+
 // the memoised primary ray of pixel (x, y): direction, and whether the ray is constant at all
 template <bool SQ = false, class A>
 DEV f3 memo_ray_of(const A& ca, const CameraConsts& c, uint32_t x, uint32_t y, bool& constant_ray) {
@@ -1551,7 +1578,7 @@ DEV void memo_from_table(const RenderArgs& a, const A& ca, const PixelState& s, 
 
 template <bool WF = false, bool SQ = false, class A>
 DEV void pixel_cache_begin(const RenderArgs& a, const A& ca, const CameraConsts& c, const PixelState& s, uint32_t* ls) {
-    if (!a.pixel_cache) return;
+    if (!a.pixel_cache || (SQ && a.pixel_cache == 4u)) return;  // (4: the memo is the pixel's table entry, read in place; SQ = a global-memory kernel)
     bool constant_ray;
     f3 rd;
     const uint32_t y = frame_row_of(ca, s.out_row);
@@ -1601,11 +1628,14 @@ DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32
     if (s.fresh) {  // wgsl:487-495: next sample of this pixel
         DIAG(1);
         uint32_t st = 0u;
-        if (cache_on)
-            with_memo<WF>(a, ls, [&](auto pc) {
+        if (cache_on) {
+            f3 mrd{0, 0, 0};
+            with_memo_ro<WF, SQ>(a, ls, s, [&](auto pc) {  // (SQ = a kernel that reads the scene from global memory)
                 st = pc[12 * 64];
-                s.rd = f3{__uint_as_float(pc[0]), __uint_as_float(pc[64]), __uint_as_float(pc[128])};
+                mrd = f3{__uint_as_float(pc[0]), __uint_as_float(pc[64]), __uint_as_float(pc[128])};
             });
+            s.rd = mrd;
+        }
         if (st & MEMO_RAY) {
             // the two disks' angle and radius draws: four steps of the generator's LCG
             // s -> s * 747796405 + 2891336453 (mod 2^32) in one, (A^4, C (A^3 + A^2 + A + 1)); exact
@@ -1651,10 +1681,10 @@ DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32
     return reuse_hit ? STEP_REUSE : STEP_TRAVERSE;
 }
 
-template <bool WF = false>
-DEV void memo_hit_load(const RenderArgs& a, uint32_t* ls, Hit& hit) {
+template <bool WF = false, bool TABLE = true>
+DEV void memo_hit_load(const RenderArgs& a, const PixelState& s, uint32_t* ls, Hit& hit) {
     TIC(t11);
-    with_memo<WF>(a, ls, [&](auto pc) {
+    with_memo_ro<WF, TABLE>(a, ls, s, [&](auto pc) {
         hit.dst = __uint_as_float(pc[3 * 64]);
         hit.point = f3{__uint_as_float(pc[4 * 64]), __uint_as_float(pc[5 * 64]), __uint_as_float(pc[6 * 64])};
         hit.normal = f3{__uint_as_float(pc[7 * 64]), __uint_as_float(pc[8 * 64]), __uint_as_float(pc[9 * 64])};
@@ -1669,10 +1699,12 @@ DEV void memo_hit_load(const RenderArgs& a, uint32_t* ls, Hit& hit) {
 }
 
 // the memoised ray's hit goes into the memo the first time it is computed
-template <bool STATS, bool WF = false>
+template <bool STATS, bool WF = false, bool TABLE = true>
 DEV void memo_hit_store(const RenderArgs& a, const PixelState& s, uint32_t* ls, const Hit& hit) {
     TIC(t13);
-    const bool cache_on = a.pixel_cache != 0;
+    // (pixel_cache == 4: the table entry already holds this hit -- a complete table has the hit of every memoised ray, so
+    // such a ray is never traversed again and there is nothing to store)
+    const bool cache_on = a.pixel_cache != 0 && !(TABLE && a.pixel_cache == 4u);
     if (cache_on && !STATS && s.seg == 0) {
         with_memo<WF>(a, ls, [&](auto pc) {
             if ((pc[12 * 64] & MEMO_RAY) == 0u) return;
@@ -1710,7 +1742,7 @@ DEV bool path_end(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_t mod
             if constexpr (FAST_MISS) {
                 if (a.fast_miss != 0u && s.seg == 0) {  // (pixel_cache != 0, wave-uniform)
                     uint32_t st = 0u;
-                    with_memo(a, ls, [&](auto pc) { st = pc[12 * 64]; });
+                    with_memo_ro<false, !LDS>(a, ls, s, [&](auto pc) { st = pc[12 * 64]; });
                     if ((st & (MEMO_RAY | MEMO_HIT_VALID)) == (MEMO_RAY | MEMO_HIT_VALID))
                         again = (uint32_t)(a.params.rays_per_pixel - 1 - s.j);
                 }
@@ -1831,7 +1863,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
         if ((!PARK || resume_slot == 0xffffffffu) && a.pixel_cache != 0u && s.fresh && a.params.number_of_bounces >= 0) {
             uint32_t st = 0u;
             f3 rd{0, 0, 0};
-            with_memo<false>(a, ls, [&](auto pc) {
+            with_memo_ro<false, !LDS>(a, ls, s, [&](auto pc) {
                 st = pc[12 * 64];
                 rd = f3{__uint_as_float(pc[0]), __uint_as_float(pc[64]), __uint_as_float(pc[128])};
             });
@@ -1846,7 +1878,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
                 Hit mh;
                 mh.hit = false;
                 mh.suspended = false;
-                memo_hit_load<false>(a, ls, mh);
+                memo_hit_load<false, !LDS>(a, s, ls, mh);
                 reused_pre = true;
                 if (path_end<LDS, total_in_lds(LDS), SIMPLE, true>(a, s, ls, STEP_REUSE, mh, n_segments, &more_reused)) return PATH_PIXEL_DONE;
             }
@@ -1864,7 +1896,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
     hit.hit = false;
     hit.suspended = false;
     if (mode == STEP_REUSE) {
-        memo_hit_load<false>(a, ls, hit);
+        memo_hit_load<false, !LDS>(a, s, ls, hit);
     } else if (mode == STEP_TRAVERSE) {
         TIC(t0);
         Isect I;
@@ -1890,7 +1922,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
                 TOC(t20, 20);
             }
         }
-        memo_hit_store<STATS>(a, s, ls, hit);
+        memo_hit_store<STATS, false, !LDS>(a, s, ls, hit);
     } else if (PARK && !TLAS && mode == STEP_RESUME) {
         // behind the deferred mesh's walk: offer the walk's hit (the local ray: the operations of ITEM_NEW_XFORM),
         // finish the segment
@@ -1909,7 +1941,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
             isect_offer(I, a.defer_mesh, walked, whp, wdst);
         }
         hit = isect_finish<LDS, SIMPLE, HYB>(a, I, s.ro, s.rd);
-        memo_hit_store<STATS>(a, s, ls, hit);
+        memo_hit_store<STATS, false, !LDS>(a, s, ls, hit);
         TOC(t22, 22);
     }
     return path_end<LDS, total_in_lds(LDS), SIMPLE, !STATS>(a, s, ls, mode, hit, n_segments, &more_reused) ? PATH_PIXEL_DONE : PATH_CONTINUE;
@@ -1978,7 +2010,9 @@ DEV void park_load(const RenderArgs& a, uint32_t slot, PixelState& s, uint32_t* 
     if constexpr (TOTAL_LDS) {
         ls[0] = fbits(p6.x); ls[64] = fbits(p6.y); ls[128] = fbits(p6.z); ls[192] = fbits(p6.w);
     }
-    if (a.pixel_cache != 0u && a.primary_complete != 0u) {
+    if (a.pixel_cache == 4u) {
+        // (the memo is the pixel's table entry, read in place)
+    } else if (a.pixel_cache != 0u && a.primary_complete != 0u) {
         const ColdArgs& ca = cold_args();
         memo_from_table(a, ca, s, frame_row_of(ca, s.out_row), ls);
     } else if (a.pixel_cache != 0u) {

@@ -594,6 +594,38 @@ def test_pipelined_single_frames_global_memory_scene(rt, tracer):
             assert np.array_equal(bits(outs[0][0]), bits(o[0])) and outs[0][1] == o[1]
 
 
+def test_burst_after_an_idle_frame_with_the_memo_in_global_memory(rt, tracer, cornell):
+    """pixel_cache = 2 (the per-wave primary-ray memo in global memory, stateful across a pixel's samples): a frame that
+    finds the stream idle takes the plain launch on the handle's stream, and the pipelined frames behind it do not wait
+    for it -- so they must not share its memo (slot 0 used to).  Bursts of frames big enough to overlap,
+    a synchronisation before each burst, pipeline on == off bit for bit."""
+    w, h = 960, 544
+    tracer.load_scene(cornell)
+    outs = []
+    try:
+        tracer.set_option("frame_ahead", 0)
+        tracer.set_option("pixel_cache", 2)
+        for pipe in (0, 4, 2):
+            tracer.set_option("pipeline", pipe)
+            tracer.write_image(np.zeros((h, w, 4), np.float32))
+            got = []
+            f = 0
+            for burst in (2, 3, 5, 2):
+                tracer.synchronize()             # the next call finds the stream idle
+                for _ in range(burst):
+                    tracer.render(rt.make_params(w, h, 4, 6, skybox=1, frames=f))
+                    f += 1
+                got.append(tracer.read_image(w, h).copy())
+            outs.append(got)
+    finally:
+        tracer.set_option("pipeline", 1)
+        tracer.set_option("pixel_cache", 1)
+        tracer.set_option("frame_ahead", -1)
+    for o in outs[1:]:
+        for k, (g, wnt) in enumerate(zip(o, outs[0])):
+            assert np.array_equal(bits(g), bits(wnt)), k
+
+
 def test_snapshot_is_the_frame_of_its_call_while_later_frames_render(rt, cornell):
     """rt_snapshot_image / rt_read_snapshot: the snapshot taken behind frame k is frame k -- bit for bit -- although
     frames k + 1.. were queued before it was read (the reference's host shows every frame: src/rendering/renderer.rs),
