@@ -181,10 +181,14 @@ typedef struct rt_stats {
     float kernel_ms;         /* sum of the hipEvent times of `launches` render launches (pipelined single frames --
                               * option "pipeline" -- overlap: their sum then exceeds the wall time) */
     uint32_t launches;       /* render launches since the last rt_reset_timing */
-    uint32_t frames;         /* frames those launches rendered (rt_render_frames: several per launch) */
+    uint32_t frames;         /* frames the host asked for since the last rt_reset_timing (rt_render_frames: several per launch) */
     uint64_t segments_reused; /* of `segments`: primary segments whose hit was taken from the per-pixel memo
                                * (same ray as the pixel's first sample: no traversal ran); segments -
                                * segments_reused rays were traversed */
+    uint32_t frames_speculative; /* frames rendered AHEAD of the host's calls (option "frame_ahead") that no call has asked for
+                               * (yet): the launches, rays and times above include them; a sequence that ends mid-batch
+                               * leaves them here */
+    uint32_t _reserved;
 } rt_stats;
 
 /* ≙ RayTracer::new + create_gpu_resources (ray_tracer.rs:49,316): picks the
@@ -277,8 +281,10 @@ int rt_get_stats(rt_handle* h, rt_stats* out);
 /* Shape of the last render launch (what a profile summary needs next to the code object's static resources):
  * out[0] = dynamic LDS bytes per workgroup, out[1] = workgroups of the render kernel, out[2] = 1 when the scene blob
  * was staged into LDS, out[3] = bit 0: many-mesh kernels, bit 1: specialised instantiation, bit 2: one-wave-per-tile
- * variant, bit 3: a deferred-walk sequence ran, bit 4: a wavefront sequence ran (then out[0] / out[1] are the walk kernel's). */
-int rt_last_launch(rt_handle* h, uint32_t out[4]);
+ * variant, bit 3: a deferred-walk sequence ran, bit 4: a wavefront sequence ran (then out[0] / out[1] are the walk kernel's);
+ * out[4] = MiB of device memory the handle holds on its own initiative right now (batch and pipeline scratch images, primary
+ * tables, global-memory memos, park queues, snapshot: what option "max_device_mb" bounds), out[5] = that cap (0 = none). */
+int rt_last_launch(rt_handle* h, uint32_t out[6]);
 /* Zero the counters and forget the recorded launch times. */
 int rt_reset_timing(rt_handle* h);
 /* Run this handle's work on a caller-owned HIP stream (e.g. the stream a
@@ -307,6 +313,12 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *   primary_hits          0 / 1 (1)               the primary table also holds every pixel's primary HIT (once per camera, frame
  *                                                 size, strip layout and scene): while the camera stands still no primary ray is
  *                                                 traversed at all; 0: a pixel's first sample of every frame traverses it again
+ *   max_device_mb         >= 0 (0)                upper bound (MiB) on the device memory the library takes on its OWN initiative: batch
+ *                                                 and pipeline scratch images (64 x 33 MB for a 1080p batch), primary tables (133 MB),
+ *                                                 global-memory memos, the park queues of deferred walks (up to half of the free
+ *                                                 memory), the snapshot; not the image, the scene and the textures.  What does not
+ *                                                 fit runs the plainer path -- smaller batches, no pipeline, no table, no deferred
+ *                                                 walks: same image, other frame time; rt_last_launch reports what is held.  0 = no cap
  *   memo_in_table         0 / 1 (1)               kernels whose memo has no room in LDS read it in place from a complete primary
  *                                                 table instead of copying it into a buffer in global memory (round 5: that copy
  *                                                 was 96 % of what those kernels wrote to memory); 0: the copy
@@ -336,18 +348,27 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 the call for frame f renders frames f .. f + d - 1 in one batched launch and blends
  *                                                 frame f; the next d - 1 calls only blend theirs (the image after every call is
  *                                                 bit-identical; a call that does not continue the sequence drops the rest).  -1 =
- *                                                 automatic: only for an LDS-resident scene and a share too small for a launch of its
- *                                                 own to keep the lanes full (batches of about 4 ms: 28 / 14 / 7 frames for a strip
- *                                                 share of 8 / 4 / 2 ranks of config 2, none for the whole frame -- except for a host
- *                                                 that WAITS for every frame, i.e. whose calls find the stream idle twice in a row:
- *                                                 batches of about 8 ms there, config 2: 7 frames), reached by doubling from 2 so
- *                                                 that a sequence of n frames renders at most n in vain; for a scene read from
- *                                                 global memory (many meshes, a big mesh) up to 8 frames and about 33 ms by a work
- *                                                 estimate, nothing for frames of 8 ms and more; 0 = off.  The counters of
- *                                                 rt_get_stats count a batch when it is launched
- *   cross_prune           0 / 1 (1)               many-mesh kernels: boxes and meshes whose entry distance lies beyond a bound derived
+ *                                                 automatic: ONLY for a host that runs ahead of the device (the call finds the
+ *                                                 handle's stream busy) -- a host that renders, waits and renders again never has a
+ *                                                 frame held back behind frames it has not asked for (round 5; before, its longest
+ *                                                 wait grew from 1.5 to 8 ms) and opts in with an explicit depth --, and then for an
+ *                                                 LDS-resident scene and a share too small for a launch of its own to keep the lanes
+ *                                                 full (batches of about 4 ms: 28 / 14 / 7 frames for a strip share of 8 / 4 / 2 ranks
+ *                                                 of config 2, none for the whole frame), reached by doubling from 2 so that a
+ *                                                 sequence of n frames renders at most n in vain; for a scene read from global memory
+ *                                                 (many meshes, a big mesh) up to 8 frames and about 33 ms by a work estimate, nothing
+ *                                                 for frames of 8 ms and more; 0 = off; 2 .. 64 = that many frames per batch whatever
+ *                                                 the host does (the first call of a batch returns its frame after the whole batch).
+ *                                                 rt_get_stats: `frames` counts the frames asked for, `frames_speculative` the ones
+ *                                                 rendered ahead that no call has asked for (yet); rays and times include both
+ *   cross_prune           0 / 1 (0)               many-mesh kernels: boxes and meshes whose entry distance lies beyond a bound derived
  *                                                 from the closest hit so far (error budget + 12.5 % slack) are not
- *                                                 entered; never in the counter / debug kernels
+ *                                                 entered; never in the counter / debug kernels.  OFF by default since round 5: exact
+ *                                                 on every random ray ever compared (102 G), but a ray that grazes a far triangle at
+ *                                                 about 1e-6 rad from an origin within about 1e-4 of that triangle's plane, in a
+ *                                                 generic orientation, gets a t from the shader's own arithmetic that the 12.5 % do
+ *                                                 not cover (tests/test_gpu_prune_directed.py: 1 texel in 2 M such rays).  1 = take
+ *                                                 the 35-45 % shorter many-mesh frames and that risk
  *   batch_frames          1..64 (32)              frames per launch of rt_render_frames
  *   batch_tile_major      0 / 1 (1)               a batch's work items in (tile, frame) order instead of (frame, tile)
  *   forest                0 / 1 (1)  (upload)     BVH meshes of one local space walked per lane back to back
@@ -392,33 +413,10 @@ int rt_set_counters(rt_handle* h, int enabled);
 void* rt_device_image(rt_handle* h);
 void* rt_stream(rt_handle* h);
 
-/* Test-only: the device's evaluation of the kernels' arithmetic building blocks, element-wise over
- * host arrays of n floats (bit patterns for integer inputs/outputs).  fn: 0 log, 1 cos, 2 sin, 3 exp,
- * 4 exp2, 5 log2, 6 pow(x,y), 7 acos, 8 atan2(x,y), 9 sqrt, 10 x/y, 11 rand() from RNG state bits x,
- * 12 next_random_number of state x (bits), 13 trig_signbits(x) (bits), 14 rand_normal_dist() from
- * state x, 15 f32(u32 bits x) * 2^-32, 16 normalize(x, y, x*y).x, 17 the kernels' reciprocal rcp_(x), 18 their
- * sqrt_dev(x).  The second call filters one RGBA8 sRGB texture at n (u, v) pairs (wgsl:455 as csrc/rt_texture.h defines
- * it).  The third compares the kernels' short reciprocal (which = 0) / square root (which = 1) with the compiler's IEEE
- * 1.0f / x / sqrt on the device for EVERY float in the range the short form serves, and the sky's three shortcuts
- * (which = 2, 3, 4: wgsl:215-218 with the branches of smoothstep / pow taken apart) with their literal forms for every
- * float in [-1.5, 1.5] / [0, 1.5]: out3 = {floats checked, mismatches, a mismatching bit pattern}. */
-int rt_test_device_units(rt_handle* h, int fn, const float* x, const float* y, float* out, uint64_t n);
-int rt_test_sweep(rt_handle* h, int which, uint64_t* out3);
-int rt_test_device_sample_texture(rt_handle* h, const rt_texture_desc* tex, const float* uv, float* rgba_out,
-                                  uint64_t n);
-
-/* Test-only: raw copy of a buffer of the last wavefront sequence (which: 0 path state, 1 hit records, 2 the two slot
- * lists, 3 the per-round list counts; layouts in csrc/rt_device.h), or (which = 4) the pixels parked in front of each round
- * of the last deferred-walk sequence (72 u32), or (which = 5, 6) the park records of its even / odd rounds. */
-int rt_test_read_wavefront(rt_handle* h, int which, void* out, uint64_t bytes);
-/* The grouped ncclSend / ncclRecv gather of rt_render_multi against the RCCL-shaped library at `lib_path`, on fake
- * buffers and without any HIP call (runs without a GPU): checks that a failure inside the group still closes the group
- * and aborts the communicators.  Error text: rt_last_error(NULL). */
-int rt_test_rccl_gather(const char* lib_path, int n_ranks);
-/* The automatic depth of option "frame_ahead" for a one-frame call that continues an accumulation (no GPU needed): the
- * scene staged in LDS (1) or read from global memory (0), the texels of the call's share, samples per pixel, bounces,
- * and whether the host counts as one that waits for every frame.  0 = the call renders its own frame only. */
-int rt_test_frame_ahead_depth(int lds_scene, uint64_t texels, int rays_per_pixel, int number_of_bounces, int host_waits);
+/* The test-only entry points (rt_test_*: the kernels' arithmetic building blocks evaluated element-wise on the device, raw
+ * copies of sequence buffers, the RCCL gather against a stub, the frame_ahead policy) are NOT exported by the product
+ * library: include/rt_test_abi.h declares them and ray_tracer_2_amd/librt2_mi355x_test.so -- the same sources compiled
+ * with -DRT_TEST_ENTRIES=1 -- exports them beside everything declared here (round 5). */
 
 const char* rt_last_error(rt_handle* h);
 void rt_destroy(rt_handle* h);

@@ -18,6 +18,6 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from ._abi import (CameraUniform, Material, MeshUniform, Node, PackedTriangle, Params,  # noqa: F401
                    SceneUniform, Sphere, make_params)
-from .lib import LIB_PATH, RtError, load  # noqa: F401
+from .lib import LIB_PATH, RtError, load, load_test  # noqa: F401
 from .ray_tracer import RayTracer, read_multi_frame, render_multi  # noqa: F401
 from .scene import Scene, SceneArrays, material, transform  # noqa: F401

@@ -76,7 +76,8 @@ class CameraDesc(C.Structure):  # CameraDescriptor, camera.rs:38-66
 
 class Stats(C.Structure):
     _fields_ = [("segments", C.c_uint64), ("paths", C.c_uint64), ("node_tests", C.c_uint64),
-                ("triangle_tests", C.c_uint64), ("kernel_ms", f32), ("launches", u32), ("frames", u32), ("segments_reused", C.c_uint64)]
+                ("triangle_tests", C.c_uint64), ("kernel_ms", f32), ("launches", u32), ("frames", u32), ("segments_reused", C.c_uint64),
+                ("frames_speculative", u32), ("_reserved", u32)]
 
 
 EXPECTED_SIZES = {Params: 48, Material: 96, Sphere: 112, MeshUniform: 240, Node: 48,

@@ -20,7 +20,7 @@ PRODUCT_SOURCES = [
 PRODUCT_HEADERS = [
     "rt_transc.h", "rt_texture.h", "rt_srgb_lut.h", "rt_device.h", "rt_rccl.h", "host/glam_math.h",
     "host/obj_loader.h", "host/bvh.h", "host/scene.h", "host/ray_tracer.hpp",
-    "../../include/rt_abi.h", "experiments/rt_wavefront.inl", "experiments/rt_wavefront_launch.inl",
+    "../../include/rt_abi.h", "../../include/rt_test_abi.h", "experiments/rt_wavefront.inl", "experiments/rt_wavefront_launch.inl",
 ]
 
 
@@ -74,6 +74,15 @@ def build_product(force=False, extra_flags=(), out=None, jobs=4):
     if todo or _newer(out, objs):
         _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-ldl", "-o", out])
     return out
+
+
+TEST_SO = os.path.join(ROOT, "ray_tracer_2_amd", "librt2_mi355x_test.so")
+
+
+def build_test_library(force=False):
+    """librt2_mi355x_test.so: the product's sources and flags plus -DRT_TEST_ENTRIES=1 -- the test-only entry points of
+    include/rt_test_abi.h, which the product library does not export (round 5)."""
+    return build_product(force=force, extra_flags=("-DRT_TEST_ENTRIES=1",), out=TEST_SO)
 
 
 CLASS_DRIVER_SO = os.path.join(ROOT, "tests", "_build", "librt2_class_driver.so")

@@ -49,7 +49,7 @@ namespace {
 __device__ unsigned long long g_wave_times[2 * 8192];  // (start, end) s_memrealtime per persistent wave
 #endif
 #if defined(RT_DIAG) || defined(RT_DIAGT)
-__device__ unsigned long long g_diag[64];
+__device__ unsigned long long g_diag[128];
 #endif
 #if defined(RT_DIAGT)
 // Timing build (-DRT_DIAGT=1, tools/diag.py --time): wave-cycles per code section.
@@ -1219,6 +1219,7 @@ enum : uint32_t {
 
 DEV f4 sample_texture(const RenderArgs& a, int index, float u, float v) {
     float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    DIAG(26);
     if (index >= 0 && (uint32_t)index < a.n_textures) {
         // global-address-space pointers: global_load, not flat_load
         typedef const __attribute__((address_space(1))) uint32_t* GWords;
@@ -1530,6 +1531,7 @@ template <bool WF = false, bool TABLE = true, class F>
 DEV void with_memo_ro(const RenderArgs& a, uint32_t* ls, const PixelState& s, F&& f) {
     if constexpr (!WF && TABLE) {
         if (a.pixel_cache == 4u) {  // wave-uniform
+            DIAG(20);
             ColdArgs& ca = cold_args();
             f(TableMemo{(TableMemo::P)a.primary + primary_index(ca.params.width, s.x, frame_row_of(ca, s.out_row)) * 16u});
             return;
@@ -1568,6 +1570,7 @@ DEV void memo_from_table(const RenderArgs& a, const A& ca, const PixelState& s, 
     const __attribute__((address_space(1))) u32x4* v =
         (const __attribute__((address_space(1))) u32x4*)a.primary + primary_index(ca.params.width, s.x, y) * 4u;
     const u32x4 e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+    DIAG(25);
     with_memo<WF>(a, ls, [&](auto pc) {
         pc[0] = e0.x; pc[64] = e0.y; pc[2 * 64] = e0.z; pc[3 * 64] = e0.w;
         pc[4 * 64] = e1.x; pc[5 * 64] = e1.y; pc[6 * 64] = e1.z; pc[7 * 64] = e1.w;
@@ -1684,6 +1687,7 @@ DEV uint32_t path_begin(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32
 template <bool WF = false, bool TABLE = true>
 DEV void memo_hit_load(const RenderArgs& a, const PixelState& s, uint32_t* ls, Hit& hit) {
     TIC(t11);
+    DIAG(21);
     with_memo_ro<WF, TABLE>(a, ls, s, [&](auto pc) {
         hit.dst = __uint_as_float(pc[3 * 64]);
         hit.point = f3{__uint_as_float(pc[4 * 64]), __uint_as_float(pc[5 * 64]), __uint_as_float(pc[6 * 64])};
@@ -1951,6 +1955,7 @@ DEV uint32_t path_step(const RenderArgs& a, PixelState& s, uint32_t* ls, uint32_
 template <bool TOTAL_LDS>
 DEV void park_store(const RenderArgs& a, uint32_t slot, const PixelState& s, uint32_t* ls, const Isect& I) {
     float4* q = a.q_out + (size_t)(slot >> 6) * (PARK_PLANES * 64u) + (slot & 63u);
+    DIAG(22);
     auto u = [](uint32_t v) { return __uint_as_float(v); };
     f4 total = s.total;
     if constexpr (TOTAL_LDS)
@@ -1999,6 +2004,7 @@ DEV void park_load_hit(const RenderArgs& a, uint32_t slot, Isect& I, CompactHit&
 template <bool TOTAL_LDS>
 DEV void park_load(const RenderArgs& a, uint32_t slot, PixelState& s, uint32_t* ls) {
     const float4* q = a.q_in + (size_t)(slot >> 6) * (PARK_PLANES * 64u) + (slot & 63u);
+    DIAG(23);
     const float4 p0 = q[0 * 64], p1 = q[1 * 64], p2 = q[2 * 64], p3 = q[3 * 64], p4 = q[4 * 64], p5 = q[5 * 64], p6 = q[6 * 64];
     s.x = fbits(p0.x); s.out_row = fbits(p0.y); s.rng = fbits(p0.z); s.j = (int32_t)fbits(p0.w);
     s.seg = (int32_t)fbits(p1.x); s.fresh = fbits(p1.y) != 0u; s.meta = fbits(p1.z);
@@ -2322,6 +2328,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderA
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (!have && rank < pool_left) {
                     slot = pool_base + rank;
+                    DIAG(43);
                     const float4* q = a.q_in + (size_t)(slot >> 6) * (PARK_PLANES * 64u) + (slot & 63u);
                     const float4 p2 = q[2 * 64], p3 = q[3 * 64];
                     lo = mat_cols_xyz(c0, c1, c2, c3, f3{p2.x, p2.y, p2.z}, 1.0f);
@@ -2355,7 +2362,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderA
                     if (STATS) tri_tests += (int)cur_count;
                     for (uint32_t j = 0; j < cur_count; ++j) {
                         const uint32_t t = tri0 + (cur + j) * TRI_ISECT_BYTES;
-                        tri_test<8>(lo, ld, ld4<false>(a, t), ld4<false>(a, t + 16), ld4<false>(a, t + 32), cull, cur + j, b);
+                        tri_test<40>(lo, ld, ld4<false>(a, t), ld4<false>(a, t + 16), ld4<false>(a, t + 32), cull, cur + j, b);
                     }
                 } else {
                     float4 q0, q1, q2, q3;
@@ -2383,6 +2390,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderA
             }
         } else {
         while (have && cur_count == 0) {  // descend to the next leaf (traverse_mesh's step)
+            DIAG(42);
             float4 q0, q1, q2, q3;
             load_wide<false>(a, cur, q0, q1, q2, q3);
             const float da = aabb_dist(lo, inv, q0, q1, b.t);
@@ -2410,7 +2418,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderA
             if (STATS) tri_tests += (int)cur_count;
             for (uint32_t j = 0; j < cur_count; ++j) {
                 const uint32_t t = tri0 + (cur + j) * TRI_ISECT_BYTES;
-                tri_test<8>(lo, ld, ld4<false>(a, t), ld4<false>(a, t + 16), ld4<false>(a, t + 32), cull, cur + j, b);
+                tri_test<40>(lo, ld, ld4<false>(a, t), ld4<false>(a, t + 16), ld4<false>(a, t + 32), cull, cur + j, b);
             }
             if (sp == 0) {
                 have = false;
@@ -2648,10 +2656,10 @@ hipError_t diag_wave_times(unsigned long long* out) {
 #endif
 #if defined(RT_DIAG) || defined(RT_DIAGT)
 hipError_t diag_read(unsigned long long* out, bool reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 64);
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 128);
     if (e != hipSuccess) return e;
     if (reset) {
-        unsigned long long z[64] = {0};
+        unsigned long long z[128] = {0};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof(z));
     }
     return e;
@@ -2770,6 +2778,10 @@ hipError_t launch_blend_frames(const BlendArgs& b, hipStream_t stream) {
     return hipGetLastError();
 }
 
+#ifndef RT_TEST_ENTRIES
+#define RT_TEST_ENTRIES 0
+#endif
+#if RT_TEST_ENTRIES   // (the test library only: ray_tracer_2_amd/librt2_mi355x_test.so, include/rt_test_abi.h)
 // ---------------------------------------------------------------------------
 // Test-only: the device's evaluation of the implementation-defined builtins (rt_transc.h), IEEE
 // division / sqrt, the RNG and the texture filter, one element per thread, so that
@@ -2872,6 +2884,7 @@ hipError_t launch_units_texture(const uint8_t* rgba8, uint32_t width, uint32_t h
                        srgb_lut, uv, out, n);
     return hipGetLastError();
 }
+#endif  // RT_TEST_ENTRIES
 
 hipError_t launch_primary(const RenderArgs& a, void* table, bool with_hits, hipStream_t stream) {
     const uint32_t ntiles = a.tiles_x * a.tiles_y;

@@ -11,11 +11,14 @@ from . import _abi as A
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RT2_LIB lets tuning tools load an experimental build; the product is librt2_mi355x.so
 LIB_PATH = os.environ.get("RT2_LIB") or os.path.join(_HERE, "librt2_mi355x.so")
+# The test library: the same sources and flags plus -DRT_TEST_ENTRIES=1 -- everything the product exports and the test-only
+# entry points of include/rt_test_abi.h (round 5: the product library no longer carries them).
+TEST_LIB_PATH = os.path.join(_HERE, "librt2_mi355x_test.so")
 
 # every symbol include/rt_abi.h declares
 EXPORTS = [
     "rt_create", "rt_upload_scene", "rt_upload_textures", "rt_set_camera", "rt_render",
-    "rt_render_strips", "rt_render_multi", "rt_render_frames", "rt_render_strips_frames", "rt_render_multi_frames", "rt_read_multi_frame", "rt_test_device_units", "rt_test_sweep", "rt_test_device_sample_texture", "rt_test_read_wavefront", "rt_test_rccl_gather", "rt_test_frame_ahead_depth", "rt_strip_texels", "rt_assemble_strips", "rt_read_image", "rt_write_image", "rt_snapshot_image", "rt_read_snapshot",
+    "rt_render_strips", "rt_render_multi", "rt_render_frames", "rt_render_strips_frames", "rt_render_multi_frames", "rt_read_multi_frame", "rt_strip_texels", "rt_assemble_strips", "rt_read_image", "rt_write_image", "rt_snapshot_image", "rt_read_snapshot",
     "rt_synchronize", "rt_get_stats", "rt_last_launch", "rt_reset_timing", "rt_bind_image", "rt_set_stream", "rt_set_option", "rt_set_counters", "rt_device_image", "rt_stream",
     "rt_last_error", "rt_destroy", "rt_version", "rt_device_count", "rt_abi_sizes",
     "rt_scene_load_builtin", "rt_scene_create", "rt_scene_set_camera", "rt_transform_cam",
@@ -26,8 +29,24 @@ EXPORTS = [
     "rt_scene_nodes", "rt_scene_get_texture", "rt_scene_mesh_label", "rt_scene_mesh_data", "rt_scene_num_mesh_instances", "rt_scene_last_error",
     "rt_scene_destroy", "rt_upload_built_scene", "rt_scene_subdivide_meshes", "rt_export_rgba8",
 ]
+# every symbol include/rt_test_abi.h declares (the test library only)
+TEST_EXPORTS = ["rt_test_device_units", "rt_test_sweep", "rt_test_device_sample_texture", "rt_test_read_wavefront",
+                "rt_test_rccl_gather", "rt_test_frame_ahead_depth"]
 
 _lib = None
+_test_lib = None
+
+
+def load_test():
+    """The test library (include/rt_test_abi.h beside include/rt_abi.h).  A handle belongs to the library that made it:
+    RayTracer(lib=load_test()) drives a handle and the test entry points through this one."""
+    global _test_lib
+    if _test_lib is None:
+        if not os.path.exists(TEST_LIB_PATH):
+            from .build import build_test_library
+            build_test_library()
+        _test_lib = _bind(C.CDLL(TEST_LIB_PATH), with_test_entries=True)
+    return _test_lib
 
 
 def load():
@@ -45,7 +64,11 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc, gfx950). There is no fallback path.")
-    L = C.CDLL(LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH), with_test_entries=False)
+    return _lib
+
+
+def _bind(L, with_test_entries):
     P = C.POINTER
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     sig = {
@@ -60,21 +83,15 @@ def load():
         "rt_render_strips_frames": (i32, [vp, P(A.Params), u32, u32, u32]),
         "rt_render_multi_frames": (i32, [P(vp), i32, P(A.Params), u32, vp]),
         "rt_read_multi_frame": (i32, [vp, vp, C.c_size_t]),
-        "rt_test_device_units": (i32, [vp, i32, vp, vp, vp, u64]),
-        "rt_test_sweep": (i32, [vp, i32, vp]),
-        "rt_test_device_sample_texture": (i32, [vp, P(A.TextureDesc), vp, vp, u64]),
         "rt_strip_texels": (u64, [u32, u32, u32, u32]),
         "rt_assemble_strips": (i32, [vp, vp, u32, u32, u32]),
         "rt_read_image": (i32, [vp, vp, C.c_size_t]),
         "rt_write_image": (i32, [vp, vp, C.c_size_t]),
-        "rt_test_frame_ahead_depth": (i32, [i32, u64, i32, i32, i32]),
         "rt_snapshot_image": (i32, [vp, C.c_size_t]),
         "rt_read_snapshot": (i32, [vp, vp, C.c_size_t]),
         "rt_synchronize": (i32, [vp]),
         "rt_get_stats": (i32, [vp, P(A.Stats)]),
-        "rt_last_launch": (i32, [vp, P(u32 * 4)]),
-        "rt_test_read_wavefront": (i32, [vp, i32, vp, u64]),
-        "rt_test_rccl_gather": (i32, [C.c_char_p, i32]),
+        "rt_last_launch": (i32, [vp, P(u32 * 6)]),
         "rt_set_counters": (i32, [vp, i32]),
         "rt_set_option": (i32, [vp, C.c_char_p, i32]),
         "rt_reset_timing": (i32, [vp]),
@@ -118,6 +135,16 @@ def load():
         "rt_export_rgba8": (i32, [vp, u32, u32, vp]),
     }
     assert set(sig) == set(EXPORTS)
+    if with_test_entries:
+        sig.update({
+            "rt_test_device_units": (i32, [vp, i32, vp, vp, vp, u64]),
+            "rt_test_sweep": (i32, [vp, i32, vp]),
+            "rt_test_device_sample_texture": (i32, [vp, P(A.TextureDesc), vp, vp, u64]),
+            "rt_test_frame_ahead_depth": (i32, [i32, u64, i32, i32, i32]),
+            "rt_test_read_wavefront": (i32, [vp, i32, vp, u64]),
+            "rt_test_rccl_gather": (i32, [C.c_char_p, i32]),
+        })
+        assert set(sig) == set(EXPORTS) | set(TEST_EXPORTS)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # raises AttributeError if the symbol is missing
         fn.restype = res
@@ -128,7 +155,6 @@ def load():
                                     A.PackedTriangle, A.CameraUniform, A.SceneUniform)]
     if list(sizes) != expect:
         raise ImportError(f"ABI mismatch: library {list(sizes)} vs bindings {expect}")
-    _lib = L
     return L
 
 

@@ -20,8 +20,8 @@ from .scene import Scene, SceneArrays
 
 
 class RayTracer:
-    def __init__(self, device=0, max_width=1920, max_height=1080):
-        self._L = load()
+    def __init__(self, device=0, max_width=1920, max_height=1080, lib=None):
+        self._L = lib or load()   # (lib=load_test(): a handle of the test library, for the rt_test_* entry points)
         self._h = C.c_void_p()
         rc = self._L.rt_create(device, max_width, max_height, C.byref(self._h))
         if rc < 0:
@@ -166,11 +166,12 @@ class RayTracer:
 
     def last_launch(self):
         """Shape of the last render launch: dynamic LDS bytes per workgroup, workgroups, scene staged in LDS, kernel flags."""
-        out = (C.c_uint32 * 4)()
+        out = (C.c_uint32 * 6)()
         self._check(self._L.rt_last_launch(self._h, C.byref(out)))
         return {"lds_bytes_per_workgroup": out[0], "workgroups": out[1], "scene_in_lds": bool(out[2]),
                 "many_mesh": bool(out[3] & 1), "specialised": bool(out[3] & 2), "one_wave_per_tile": bool(out[3] & 4),
-                "deferred_walks": bool(out[3] & 8), "wavefront": bool(out[3] & 16)}
+                "deferred_walks": bool(out[3] & 8), "wavefront": bool(out[3] & 16),
+                "device_mb_held": out[4], "device_mb_cap": out[5]}
 
     @property
     def device_image_ptr(self):

@@ -7,10 +7,16 @@ import re
 from conftest import ROOT
 
 
-def header_functions():
-    text = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
+def header_functions(header="rt_abi.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("rt_"))
 
 
 def test_every_declared_symbol_is_exported(rt):
@@ -23,12 +29,28 @@ def test_every_declared_symbol_is_exported(rt):
     assert sorted(EXPORTS) == declared
 
 
+def test_the_product_library_exports_no_test_entry_points(rt):
+    """Round 5: the rt_test_* entry points live in include/rt_test_abi.h and in
+    librt2_mi355x_test.so (the same sources + -DRT_TEST_ENTRIES=1); the product exports include/rt_abi.h and nothing else."""
+    from ray_tracer_2_amd import lib
+    product = exported_symbols(lib.LIB_PATH)
+    assert not [s for s in product if s.startswith("rt_test_")], product
+    assert not [s for s in header_functions() if s.startswith("rt_test_")]
+    declared = header_functions("rt_test_abi.h")
+    assert sorted(lib.TEST_EXPORTS) == declared and all(s.startswith("rt_test_") for s in declared)
+    T = rt.load_test()
+    for name in declared + header_functions():
+        assert hasattr(T, name), f"{name} missing from the test library"
+    # (rt_diag_* / rt_wave_times only exist in the diagnostic builds)
+    assert [s for s in product if not s.startswith("rt_scene_") and s not in header_functions()] == []
+
+
 def test_prototypes_take_as_many_arguments_as_the_header_declares(rt):
     """ctypes checks the argument COUNT of a call against argtypes: a prototype in lib.py with one argument too many makes
     every call of that function a TypeError (rt_set_stream once: only bench.py --gpus N called it)."""
-    text = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
+    text = open(os.path.join(ROOT, "include", "rt_abi.h")).read() + open(os.path.join(ROOT, "include", "rt_test_abi.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    L = rt.load()
+    L = rt.load_test()   # (every prototype of both headers; the product's bindings are the same table minus rt_test_*)
     seen = 0
     for name, args in re.findall(r"\b(rt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         args = args.strip()

@@ -8,7 +8,7 @@ W, H = 1920, 1080
 
 
 def depth(lds, texels, spp=8, bounces=4, waits=0):
-    return rt.load().rt_test_frame_ahead_depth(int(lds), texels, spp, bounces, int(waits))
+    return rt.load_test().rt_test_frame_ahead_depth(int(lds), texels, spp, bounces, int(waits))
 
 
 def share(world):
@@ -20,9 +20,10 @@ def test_config2_shares_of_a_strip_split():
     # batches of about 4 ms of LDS-resident rays: 28 / 14 / 7 frames for a share of 8 / 4 / 2 ranks, none for the whole frame
     assert [depth(True, share(w)) for w in (8, 4, 2)] == [28, 14, 7]
     assert depth(True, W * H) == 0
-    # ... unless the host waits for every frame: about 8 ms, i.e. 7 frames of config 2
-    assert depth(True, W * H, waits=1) == 7
-    assert depth(True, share(8), waits=1) == 56
+    # a host that WAITS for every frame (its calls find the stream idle) never has a frame held back behind frames it has
+    # not asked for (round 5): nothing is rendered ahead for it unless it sets an explicit depth
+    assert depth(True, W * H, waits=1) == 0
+    assert depth(True, share(8), waits=1) == 0
     # a small window: as many as a launch takes
     assert depth(True, 320 * 180) == 64
 
@@ -33,7 +34,7 @@ def test_scenes_read_from_global_memory():
     assert depth(False, W * H, spp=16) == 0         # config 3 stand-in: estimated at 11 ms per frame
     assert depth(False, 3840 * 2160, spp=64, bounces=8) == 0
     assert depth(False, share(8)) == 8 and depth(False, 320 * 180) == 8
-    assert depth(False, W * H, waits=1) == 5        # (the waiting-host rule is the LDS scenes')
+    assert depth(False, W * H, waits=1) == 0        # (a waiting host: nothing ahead)
 
 
 def test_nothing_to_render_ahead():

@@ -70,6 +70,15 @@ def edge_states():
     return np.array([state_before(0)] + [state_before(r) for r in range(0xffffff80, 0x100000000)], np.uint32)
 
 
+@pytest.fixture(scope="module")
+def tracer(rt):
+    """A handle of the TEST library (librt2_mi355x_test.so: the product's sources and flags + the rt_test_* entry points of
+    include/rt_test_abi.h, which the product library does not export)."""
+    t = rt.RayTracer(device=0, max_width=64, max_height=64, lib=rt.load_test())
+    yield t
+    t.close()
+
+
 def test_rand_conversion_over_every_exponent_and_both_ends(tracer, oracle, rng):
     """f32(r) * 2^-32 on the device == f32(r) / 4294967295.0 on the host for raw generator outputs r:
     10^7 random ones, every r that rounds to 2^32 (rand() == 1.0), r = 0 (rand() == 0.0), and the

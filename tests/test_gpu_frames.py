@@ -561,7 +561,10 @@ def test_frames_rendered_ahead_leave_the_same_image_after_every_call(rt, oracle,
             assert len(got) == len(want)
             for k, (g, wnt) in enumerate(zip(got, want)):
                 assert np.array_equal(bits(g), bits(wnt)), (ahead, k)
-            assert st.launches < st.frames   # (frames were rendered ahead: fewer launches than frames)
+            if ahead > 0:
+                assert st.launches < st.frames   # (frames were rendered ahead: fewer launches than frames)
+            else:   # automatic: this script reads -- waits for -- most frames; nothing is rendered ahead for a host that waits
+                assert st.launches <= st.frames
     finally:
         tracer.set_option("frame_ahead", -1)
     ref = np.zeros((h, w, 4), np.float32)

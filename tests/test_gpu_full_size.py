@@ -120,13 +120,13 @@ def test_config4_standin_at_full_size(rt, oracle):
         ref, _ = _oracle_rows(oracle, rt, a, W, H, nb, spp, rows, 1)
         assert np.array_equal(bits(one[rows]), bits(ref))
         assert W * H * spp <= s.segments <= W * H * spp * (nb + 1) and np.isfinite(one).all()
-        # cross-mesh pruning (on by default: `one` is a pruned frame) against the shader's unconditional walk:
+        # cross-mesh pruning (opt-in since round 5: `one` is the shader's unconditional walk) against it:
         # the WHOLE frame, GPU against GPU
-        tr.set_option("cross_prune", 0)
+        tr.set_option("cross_prune", 1)
         tr.reset_timing()
         tr.render(p)
         assert np.array_equal(bits(tr.read_image(W, H)), bits(one)) and tr.stats().segments == s.segments
-        tr.set_option("cross_prune", 1)
+        tr.set_option("cross_prune", 0)
         # three accumulated frames in one launch
         few = rows[[1, 33, 67, 101, 134]]
         tr.write_image(np.zeros((H, W, 4), np.float32))

@@ -211,10 +211,10 @@ def test_config2_whole_frame_accumulated(rt, oracle, tracer, cornell):
         want_rays += st.segments
         tracer.render(p)
         assert np.array_equal(bits(tracer.read_image(W, H)), bits(ref)), f
-    # (default options: a call that continues the accumulation and finds the stream idle renders the next frames with
-    # its own -- option frame_ahead; the counters count what was launched)
+    # (default options: this host reads -- waits for -- every frame, so every frame is a launch of its own and the counters
+    # are exactly these frames'; round 4 rendered frames ahead for such a host and the equality had to be relaxed)
     st = tracer.stats()
-    assert st.segments >= want_rays and st.launches < NF
+    assert st.segments == want_rays and st.launches == NF and st.frames == NF and st.frames_speculative == 0
     tracer.set_option("frame_ahead", 0)   # one launch per frame: exactly these rays
     try:
         tracer.write_image(np.zeros((H, W, 4), np.float32))
@@ -808,7 +808,7 @@ def test_cross_mesh_pruning_and_foreign_hierarchies(rt, oracle, tracer):
             if counters:
                 assert (s.node_tests, s.triangle_tests) == (st.node_tests, st.triangle_tests), name
         tracer.set_counters(False)
-        tracer.set_option("cross_prune", 1)
+        tracer.set_option("cross_prune", 0)   # (the default since round 5)
 
 
 def test_config4_sponza_sized_standin(rt, oracle, tracer):

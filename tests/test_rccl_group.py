@@ -22,7 +22,7 @@ sys.path.insert(0, {root!r})
 from ray_tracer_2_amd.build import build_fake_rccl
 import ray_tracer_2_amd.lib as lib
 so = build_fake_rccl()
-L = lib.load()
+L = lib.load_test()   # (rt_test_rccl_gather: include/rt_test_abi.h, the test library)
 fake = ctypes.CDLL(so)   # the same mapping the product dlopens: shared counters
 def state():
     out = (ctypes.c_int * 8)()
@@ -74,6 +74,6 @@ def test_failing_group_end_and_group_start():
 
 def test_missing_library_is_an_error_not_a_crash():
     import ray_tracer_2_amd.lib as lib
-    L = lib.load()
+    L = lib.load_test()
     assert L.rt_test_rccl_gather(b"/nonexistent/librccl.so", 2) == -6   # RT_ERR_IO
     assert b"cannot load librccl" in L.rt_last_error(None)

@@ -14,7 +14,8 @@ from ray_tracer_2_amd import scenes  # noqa: E402
 
 UPLOAD_OPTS = {"tlas", "tlas_min", "forest", "flat2"}
 DEFAULTS = {"primary_table": 1, "tlas": 1, "tlas_min": 8, "forest": 1, "stack_wide": -1, "tile_feedback_period": 8, "kernel_variant": -1,
-            "lds_scene": 1, "tile_feedback": 1, "cull_roots": -1, "pixel_cache": 1, "vote_eighths": -1, "vote_patience": -1, "lds_top": 0, "flat2": 1, "batch_tile_major": 1, "sort_rounds": 0}
+            "lds_scene": 1, "tile_feedback": 1, "cull_roots": -1, "pixel_cache": 1, "vote_eighths": -1, "vote_patience": -1, "lds_top": 0, "flat2": 1, "batch_tile_major": 1, "sort_rounds": -1,
+            "memo_in_table": 1, "cross_prune": 0, "primary_hits": 1}
 
 
 def main():

@@ -65,6 +65,7 @@ def main():
         tr.synchronize()
         ts.append((time.perf_counter() - t1) / frames * 1e3)
         st = tr.stats()
+    out["frames_total"] = max(2, batch) + 3 * frames   # (every frame this run renders before the counter frame: tools/pmc_scene.sh)
     ms = statistics.median(ts)
     rays = st.segments / st.frames
     out.update(ms_per_frame=ms, kernel_ms_per_frame=st.kernel_ms / st.frames, rays_per_frame=rays,

@@ -71,7 +71,7 @@ def main():
     tr.load_scene(arrays)
     tr.set_option("kernel_variant", variant)
     L = rt.load()
-    buf = (C.c_uint64 * 64)()
+    buf = (C.c_uint64 * 128)()
     L.rt_diag_read(tr._h, buf, 1)
     if batch > 1:
         tr.render_frames(rt.make_params(W, H, 4, spp, skybox=1, frames=0), batch)

@@ -22,7 +22,7 @@ arrays = rt.SceneArrays.from_scene(scenes.cornell_dragon(scenes.load_raw_meshes(
                                                          scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")),
                                                          subdivide=n, device=0 if n > 3 else None))
 W, H = 1920, 1080
-tr = rt.RayTracer(0, W, H)
+tr = rt.RayTracer(0, W, H, lib=rt.load_test())   # (rt_test_read_wavefront: the test library)
 tr.set_option("batch_frames", batch)
 tr.set_option("sort_rounds", rounds)
 tr.load_scene(arrays)

@@ -31,15 +31,16 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         per[r["Kernel_Name"][:90]].append(float(r["Counter_Value"]))
 try:
     j = json.load(open(d + ".json"))
-    fpl, ms = j.get("frames_per_launch", 1), j.get("ms_per_frame", 0.0)
+    fpl, ms, ft = j.get("frames_per_launch", 1), j.get("ms_per_frame", 0.0), j.get("frames_total", 0)
 except Exception:
-    fpl, ms = 1, 0.0
+    fpl, ms, ft = 1, 0.0, 0
 k = 2048 if ctr == "FETCH_SIZE" else 1024
 print(f"[{opt or 'default'}] {ctr}  ({fpl} frames per launch, {ms:.3f} ms/frame under the profiler)")
 for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
     if sum(v) * k < 1e6:
         continue
-    print(f"    {name:90s} launches {len(v):4d}  total {sum(v) * k / 1e6:10.1f} MB  mean per launch {sum(v) / len(v) * k / 1e6:9.1f} MB")
+    print(f"    {name:90s} launches {len(v):4d}  total {sum(v) * k / 1e6:10.1f} MB  mean per launch {sum(v) / len(v) * k / 1e6:9.1f} MB"
+          + (f"  = {sum(v) * k / 1e6 / ft:8.1f} MB per frame ({ft} frames)" if ft else ""))
 PY
   done
 done

@@ -23,7 +23,7 @@ tr = rt.RayTracer(0, W, H)
 tr.set_option("wavefront", 1)
 tr.load_scene(arrays)
 L = rt.load()
-buf = (C.c_uint64 * 64)()
+buf = (C.c_uint64 * 128)()
 p = rt.make_params(W, H, 4, 8, skybox=1, frames=0)
 tr.render(p)
 L.rt_diag_read(tr._h, buf, 1)
