@@ -10,7 +10,9 @@ calculate_ray_collions call (wgsl:353), counted exactly on the device; the
 segments whose hit is taken from the per-pixel primary-ray memo (no traversal)
 are counted too and `Mrays_traversed/s` is reported beside the headline.
 
-The timed region renders K frames with rt_render_frames: frames are sampled in
+The window of K frames between two fences (barrier + synchronize) is timed `--repeats` times (default 5, each window
+continuing the accumulation): `ms_per_step` and `value` are the MEDIAN window's, `timing` carries min / max / every window.
+A window renders its K frames with rt_render_frames: frames are sampled in
 batches (default 32 per launch) by ONE persistent launch over (frame, tile) work
 items and blended in frame order by a dense second kernel -- bit-identical to K
 single-frame launches (tests/test_gpu_frames.py).  The single-frame
@@ -119,7 +121,7 @@ def live_traffic(args):
     frames = 32
     child = [sys.executable, os.path.abspath(__file__), "--steps", "64", "--warmup", "32", "--batch", str(frames),
              "--width", str(args.width), "--height", str(args.height),
-             "--no-cpu-baseline", "--no-extras", "--no-per-frame-leg", "--no-live-traffic"]
+             "--no-cpu-baseline", "--no-extras", "--no-per-frame-leg", "--no-live-traffic", "--repeats", "1"]
     out = tempfile.mkdtemp(prefix="rt2_traffic_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     sums = {}
@@ -183,7 +185,7 @@ def live_traffic(args):
         shutil.rmtree(out, ignore_errors=True)
     fetch = (sums["FETCH_SIZE"][0] + sums["FETCH_SIZE"][1]) * 1024 * 2   # KiB -> B, gfx950: x 2
     write = (sums["WRITE_SIZE"][0] + sums["WRITE_SIZE"][1]) * 1024
-    return {"valu": valu, "valu_error": valu_error, "bytes_per_launch": fetch + write, "frames_per_launch": frames, "read_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+    return {"valu": valu, "valu_error": valu_error, "kernel_name": sums["FETCH_SIZE"][3], "bytes_per_launch": fetch + write, "frames_per_launch": frames, "read_bytes_per_launch": fetch, "write_bytes_per_launch": write,
             "source": f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each, over `bench.py --steps 64 --warmup 32 "
                       f"--batch {frames}` ({sums['FETCH_SIZE'][2]} launches of {sums['FETCH_SIZE'][3][:60]} after the first, plus the blend kernel); "
                       "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (MI355X_MICROARCH.md)"}, None
@@ -194,6 +196,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the window of --steps frames is timed (ms_per_step = the median window)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the un-overlapped / first-frame measurements")
     ap.add_argument("--no-per-frame-leg", action="store_true",
@@ -328,55 +331,79 @@ def main():
 
     render(0, args.warmup)
     fence()
-    tracer.reset_timing()
-    t0 = time.perf_counter()
-    render(args.warmup, args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    st = tracer.stats()
+    # The timed region: EXACTLY `steps` frames between two fences -- and that window `repeats` times over (default 5, each
+    # continuing the accumulation), because one window of 20 frames is 23 ms of wall time: one sample.  ms_per_step / value
+    # are the MEDIAN window's (N > 1: of the windows' max-over-ranks times); min / max go into the line beside it.
+    windows = []
+    for w_i in range(max(1, args.repeats)):
+        tracer.reset_timing()
+        t0 = time.perf_counter()
+        render(args.warmup + w_i * args.steps, args.steps)
+        fence()
+        dt = time.perf_counter() - t0
+        st = tracer.stats()
+        windows.append((dt, float(st.segments), float(st.segments_reused), st.kernel_ms / max(st.launches, 1), st.frames / max(st.launches, 1)))
+    frames_done = args.warmup + max(1, args.repeats) * args.steps
 
     if world > 1 and rank == 0 and os.environ.get("RT2_BENCH_VERIFY"):
         # the stitched frame must equal the single-GPU frame (same frames sequence)
         single = rt.RayTracer(device=device, max_width=W, max_height=H)
         single.load_scene(arrays)
-        for f in range(args.warmup + args.steps):
+        for f in range(frames_done):
             single.render(rt.make_params(W, H, BOUNCES, SPP, skybox=1, frames=f))
         ref = torch.from_numpy(single.read_image(W, H)).reshape(H * W, 4)
         same = torch.equal(ref.view(torch.int32), frame.cpu().view(torch.int32))
         print(f"[verify] stitched frame bit-identical to 1-GPU frame: {same}", file=sys.stderr, flush=True)
         assert same
-    rays_local, reused_local = float(st.segments), float(st.segments_reused)
     launch_info = tracer.last_launch()                 # dynamic LDS per workgroup, grid, which instantiation ran
-    launch_ms = st.kernel_ms / max(st.launches, 1)     # render (+ blend) launch, HIP events on the tracer's stream
-    frames_per_launch = st.frames / max(st.launches, 1)
+    wt = torch.tensor(windows, dtype=torch.float64)          # [window, (elapsed, rays, reused, launch ms, frames per launch)]
+    if world > 1:
+        dev_t = "cuda" if args.backend == "nccl" else "cpu"
+        wmax, wsum = wt.to(dev_t).clone(), wt.to(dev_t).clone()
+        dist.all_reduce(wmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(wsum, op=dist.ReduceOp.SUM)
+        wt = torch.stack([wmax[:, 0], wsum[:, 1], wsum[:, 2], wmax[:, 3], wmax[:, 4]], dim=1).cpu()
+    order = sorted(range(wt.shape[0]), key=lambda i: float(wt[i, 0]))
+    mid = order[(len(order) - 1) // 2]                  # the median window (the lower one of an even count)
+    elapsed, rays_med, reused_med = float(wt[mid, 0]), float(wt[mid, 1]), float(wt[mid, 2])
+    launch_ms = float(wt[mid, 3])                       # render (+ blend) launch, HIP events on the tracer's stream
+    frames_per_launch = float(wt[mid, 4])
+    window_ms = [float(x) / args.steps * 1e3 for x in wt[:, 0]]
 
     # The same K frames once more with ONE launch (N > 1: and one gather + assemble) per frame: what a host that
     # presents every frame gets.  Outside the timed region of `value`; same barrier + synchronize bracket.
     elapsed_pf, rays_pf_local, launch_ms_pf = float("nan"), float("nan"), float("nan")
     if not args.no_per_frame_leg:
-        render(args.warmup + args.steps, 4, batch=1)       # (untimed: the pipeline's streams and scratch images are made here)
+        render(frames_done, 4, batch=1)       # (untimed: the pipeline's streams and scratch images are made here)
         fence()
         tracer.reset_timing()
         t1 = time.perf_counter()
-        render(args.warmup + args.steps + 4, args.steps, batch=1)
+        render(frames_done + 4, args.steps, batch=1)
         fence()
         elapsed_pf = time.perf_counter() - t1
         st_pf = tracer.stats()
         # (calls that continue the accumulation may have rendered frames beyond the window with their own -- option
-        # frame_ahead; the counters count what was launched: the window's share is rays per launched frame x its frames)
-        rays_pf_local = float(st_pf.segments) * args.steps / max(st_pf.frames, 1)
+        # frame_ahead; the counters count what was launched: the window's share is rays per rendered frame x its frames)
+        rays_pf_local = float(st_pf.segments) * args.steps / max(st_pf.frames + st_pf.frames_speculative, 1)
         launch_ms_pf = st_pf.kernel_ms / max(st_pf.launches, 1)
 
+    rays, reused = rays_med, reused_med
+    ranks_seen, rank_devices = 1, [torch.cuda.get_device_name(device)]
     if world > 1:
-        t = torch.tensor([elapsed, rays_local, launch_ms, reused_local, elapsed_pf, rays_pf_local, launch_ms_pf], dtype=torch.float64,
+        t = torch.tensor([elapsed_pf, rays_pf_local, launch_ms_pf], dtype=torch.float64,
                          device="cuda" if args.backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, rays, launch_ms, reused = float(tmax[0]), float(t[1]), float(tmax[2]), float(t[3])
-        elapsed_pf, rays_pf, launch_ms_pf = float(tmax[4]), float(t[5]), float(tmax[6])
+        elapsed_pf, rays_pf, launch_ms_pf = float(tmax[0]), float(t[1]), float(tmax[2])
+        # who took part: the communicator's size and every rank's device (so that a SCALE record can be checked for N ranks
+        # on N devices)
+        ranks_seen = dist.get_world_size()
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: cuda:{device} {torch.cuda.get_device_name(device)}")
+        rank_devices = names
     else:
-        rays, reused, rays_pf = rays_local, reused_local, rays_pf_local
+        rays_pf = rays_pf_local
 
     extras = {}
     if world == 1 and rank == 0 and not args.no_extras:
@@ -577,13 +604,25 @@ def main():
         # which kernel the library runs for this shape (rt_api.hip render_impl): batches always the persistent one
         cus = torch.cuda.get_device_properties(device).multi_processor_count
         tiles = ((W + 7) // 8) * (texels // W // 8 if world > 1 else (H + 7) // 8)
-        spec = "true" if launch_info["specialised"] else "false"
-        kernel = f"rt_render_persistent_kernel<true, false, false, false, {spec}>"
-        if launch_info["one_wave_per_tile"]:
-            kernel = f"rt_render_tiles_kernel<true, false, false, {spec}>"
+        if live is not None and live.get("kernel_name"):
+            # the name rocprofv3 reported for the render kernel of this run's own profiled child pass
+            kernel, kernel_src = live["kernel_name"], "rocprofv3 (the live --pmc pass of this run)"
+        else:
+            # (no profiler pass in this run -- N > 1, --no-live-traffic, tuning options: named from rt_last_launch; template
+            # arguments <LDS, STATS, TLAS, PARK, SIMPLE, HYB> of rt_kernel.hip)
+            spec = "true" if launch_info["specialised"] else "false"
+            lds = "true" if launch_info["scene_in_lds"] else "false"
+            kernel = f"void rtd::rt_render_persistent_kernel<{lds}, false, false, false, {spec}, false>(rtd::RenderArgs)"
+            if launch_info["one_wave_per_tile"]:
+                kernel = f"void rtd::rt_render_tiles_kernel<{lds}, false, false, {spec}>(rtd::RenderArgs)"
+            kernel_src = "assembled from rt_last_launch (no profiler pass in this run)"
         out = {
             "metric": "Mrays/s", "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            # the window of `steps` frames was timed `repeats` times; ms_per_step and value are the median window's
+            "timing": {"repeats": len(window_ms), "ms_per_step_median": ms_per_step, "ms_per_step_min": min(window_ms),
+                       "ms_per_step_max": max(window_ms), "ms_per_step_windows": window_ms},
+            "ranks_seen": ranks_seen, "rank_devices": rank_devices,
             # the figures to track across rounds: ms per frame (= ms_per_step), camera paths per second and the rays that
             # were actually traversed (`value` also counts the primary segments served from the per-pixel memo)
             "Mpaths/s": W * H * SPP * args.steps / elapsed / 1e6,
@@ -605,7 +644,7 @@ def main():
                     "(committed as tests/golden/cornell_scene.npz); no random inputs: the seed is Params.frames",
             "config": {"workload": f"CornellBox-Original {W}x{H}, {SPP} spp, {BOUNCES} bounces "
                                    "(BASELINE configs[1]); 8 meshes / 32 triangles / 32 BVH nodes",
-                       "frames": f"{args.warmup}..{args.warmup + args.steps - 1} (progressive accumulation)",
+                       "frames": f"{args.warmup}..{frames_done - 1} (progressive accumulation; {max(1, args.repeats)} timed windows of {args.steps})",
                        "frames_overlapped": f"{frames_per_launch:g} frames per launch (rt_render_frames: (frame, tile) work items "
                                             "+ ordered blend kernel; bit-identical to one launch per frame)"
                                             if frames_per_launch > 1 else "no: one launch per frame",
@@ -622,7 +661,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src or stale,
                          "traffic_measured_in_this_run": live is not None and traffic is not None, "traffic_live_error": live_error,
-                         "kernel": kernel, "kernel_ms": launch_ms, "frames_per_launch": frames_per_launch,
+                         "kernel": kernel, "kernel_name_source": kernel_src, "kernel_ms": launch_ms, "frames_per_launch": frames_per_launch,
                          "launch": launch_info,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "path is FP32-VALU-bound (SURVEY 8d, DESIGN.md): compulsory HBM bytes are 32 B per pixel per frame; "

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profiling recipe (run on the GPU box through gpurun):
 #   bash profiles/run_profile.sh <tag> [command ...]
-# default command: the headline bench (python3 bench.py --steps 64 --warmup 32 --batch 32 --no-cpu-baseline --no-extras --no-per-frame-leg --no-live-traffic).
+# default command: the headline bench (python3 bench.py --steps 64 --warmup 32 --batch 32 --no-cpu-baseline --no-extras --no-per-frame-leg --no-live-traffic --repeats 1).
 # Writes rocprofv3 outputs under gpurun_out/prof_<tag>/ ; profiles/summarize.py then distils them into
 # profiles/<tag>_summary.txt.  Counters are collected in their own passes (never together with a trace);
 # FETCH_SIZE and WRITE_SIZE each in a pass of their own, as MI355X_MICROARCH.md prescribes.
@@ -12,7 +12,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 # the product library must exist before the profiler starts (no compile under rocprofv3)
 python3 -m ray_tracer_2_amd.build > $OUT/build.log 2>&1 || { echo "build failed"; tail -5 $OUT/build.log; exit 1; }
-if [ $# -gt 0 ]; then CMD="$*"; else CMD="python3 $REPO/bench.py --steps 64 --warmup 32 --batch 32 --no-cpu-baseline --no-extras --no-per-frame-leg --no-live-traffic"; fi
+if [ $# -gt 0 ]; then CMD="$*"; else CMD="python3 $REPO/bench.py --steps 64 --warmup 32 --batch 32 --no-cpu-baseline --no-extras --no-per-frame-leg --no-live-traffic --repeats 1"; fi
 echo "$CMD" > $OUT/command.txt
 cd /tmp && export TMPDIR=/tmp
 fail=0
