@@ -165,3 +165,164 @@ def sponza_standin(n_meshes=200, seed=11, detail=1):
                                           emission_strength=10.0, smoothness=0.0, specular=0.0))   # scene.rs:894-908
     sc.build()
     return sc
+
+
+# ---- config 4 stand-in with the reference's real materials and textures (round 5) ---------------------------------------
+def _grid_sheet(o, du, dv, nu, nv, bump=0.0, rng=None, wave=None):
+    """nu x nv quads spanning o + a du + b dv; optional relief along the sheet's normal (random bumps, or a sine wave along u:
+    drapes).  Returns positions [n, 3], uvs [n, 2], faces [m, 3]."""
+    o, du, dv = (np.asarray(x, np.float64) for x in (o, du, dv))
+    n = np.cross(du, dv)
+    n = n / np.linalg.norm(n)
+    a, b = np.meshgrid(np.arange(nu + 1) / nu, np.arange(nv + 1) / nv, indexing="xy")
+    pos = o + a[..., None] * du + b[..., None] * dv
+    if wave is not None:
+        pos = pos + (np.sin(a * wave[0] * 2 * np.pi) * wave[1])[..., None] * n
+    if bump and rng is not None:
+        inner = ((a > 0) & (a < 1) & (b > 0) & (b < 1)).astype(np.float64)
+        pos = pos + (rng.uniform(-1, 1, a.shape) * inner * bump)[..., None] * n
+    uv = np.stack([a * max(1, nu // 4), b * max(1, nv // 4)], -1)
+    q = (np.arange(nv)[:, None] * (nu + 1) + np.arange(nu)[None, :]).reshape(-1)
+    f = np.stack([q, q + 1, q + nu + 2, q, q + nu + 2, q + nu + 1], 1).reshape(-1, 3)
+    return pos.reshape(-1, 3), uv.reshape(-1, 2), f
+
+
+def _cylinder(c, r, h, seg, rings, taper=0.0):
+    """A column: seg x rings quads around the y axis from c (base centre), radius r (tapering by `taper`), height h; open ends."""
+    th, yy = np.meshgrid(np.arange(seg + 1) / seg * 2 * np.pi, np.arange(rings + 1) / rings, indexing="xy")
+    rr = r * (1.0 - taper * yy) * (1.0 + 0.06 * np.sin(yy * 9.0))
+    pos = np.stack([c[0] + rr * np.cos(th), c[1] + yy * h, c[2] + rr * np.sin(th)], -1)
+    uv = np.stack([th / (2 * np.pi) * 2.0, yy * 4.0], -1)
+    q = (np.arange(rings)[:, None] * (seg + 1) + np.arange(seg)[None, :]).reshape(-1)
+    f = np.stack([q, q + seg + 2, q + 1, q, q + seg + 1, q + seg + 2], 1).reshape(-1, 3)
+    return pos.reshape(-1, 3), uv.reshape(-1, 2), f
+
+
+def _blob(c, r, seg, rings, squash=1.0):
+    """A vase / lion head: a lat-long sphere of radius r around c, squashed in y."""
+    th, ph = np.meshgrid(np.arange(seg + 1) / seg * 2 * np.pi, (np.arange(rings + 1) / rings) * np.pi, indexing="xy")
+    rr = r * (1.0 + 0.15 * np.sin(3 * ph))
+    pos = np.stack([c[0] + rr * np.sin(ph) * np.cos(th), c[1] - rr * np.cos(ph) * squash, c[2] + rr * np.sin(ph) * np.sin(th)], -1)
+    uv = np.stack([th / (2 * np.pi), ph / np.pi], -1)
+    q = (np.arange(rings)[:, None] * (seg + 1) + np.arange(seg)[None, :]).reshape(-1)
+    f = np.stack([q, q + seg + 2, q + 1, q, q + seg + 1, q + seg + 2], 1).reshape(-1, 3)
+    return pos.reshape(-1, 3), uv.reshape(-1, 2), f
+
+
+def _write_obj(path, mtl_name, groups, with_normals):
+    """groups: [(name, material, positions, uvs, faces)].  One `g` + `usemtl` per group (tobj 4.0.3 starts a model at each);
+    `vn` lines only when asked -- without them the loader synthesises smooth normals (src/core/asset.rs:224-261)."""
+    out = [f"mtllib {mtl_name}"]
+    base = 1
+    for name, mat, pos, uv, faces in groups:
+        out.append(f"g {name}")
+        out.append(f"usemtl {mat}")
+        out += [f"v {p[0]:.6f} {p[1]:.6f} {p[2]:.6f}" for p in pos]
+        out += [f"vt {t[0]:.6f} {t[1]:.6f}" for t in uv]
+        if with_normals:
+            nrm = np.zeros_like(pos)
+            e1, e2 = pos[faces[:, 1]] - pos[faces[:, 0]], pos[faces[:, 2]] - pos[faces[:, 1]]
+            fn = np.cross(e1, e2)
+            for k in range(3):
+                np.add.at(nrm, faces[:, k], fn)
+            nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
+            out += [f"vn {n[0]:.6f} {n[1]:.6f} {n[2]:.6f}" for n in nrm]
+            out += [f"f {a}/{a}/{a} {b}/{b}/{b} {c}/{c}/{c}" for a, b, c in faces + base]
+        else:
+            out += [f"f {a}/{a} {b}/{b} {c}/{c}" for a, b, c in faces + base]
+        base += len(pos)
+    open(path, "w").write("\n".join(out) + "\n")
+
+
+SPONZA_FIXTURES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sponza")
+
+
+def sponza_hetero(seed=5, fixtures=SPONZA_FIXTURES, workdir=None):
+    """BASELINE config 4 stand-in built from what the reference DOES hold of sponza (round 5): the 25
+    materials of assets/sponza.mtl and 25 of its textures at native resolution (tests/golden/sponza/: data fixtures), loaded
+    through the OBJ / MTL / PNG loader exactly as Scene::sponza would load sponza.obj (src/scene/scene.rs:864-910,
+    src/core/asset.rs:102-330), on PROCEDURAL geometry with sponza.obj's shape of statistics: about 390 groups of 12 to
+    about 40,000 triangles (two orders of magnitude, a few big ones holding most of the triangles), about 262 k in all --
+    flat and relief walls and floors, columns, arches, vases, lion heads, drapes.  Unlike Scene::sponza (ONE transform for the
+    whole OBJ) the groups come under FIVE transforms -- different scales, rotations, a non-uniform one -- so that runs of
+    meshes sharing a local space, top-level trees and ITEM_PRUNE are not universal.  Two OBJ files carry `vn`, three leave the
+    normals to the loader.  Plus Scene::sponza's emissive quad and sphere (scene.rs:879-908)."""
+    import tempfile
+    rng = np.random.RandomState(seed)
+    work = workdir or tempfile.mkdtemp(prefix="rt2_sponza_")
+    for name in ("sponza_standin.mtl", "textures"):
+        dst = os.path.join(work, name)
+        if not os.path.exists(dst):
+            os.symlink(os.path.join(fixtures, name), dst)
+    G = {k: [] for k in "ABCDE"}
+
+    def add(obj, name, mat, shape):
+        G[obj].append((f"{name}_{len(G[obj])}", mat, *shape))
+
+    # A: the hall (the reference's transform: scale 0.05) -- floor tiles, four relief walls (the big meshes), ceiling, columns
+    for i in range(6):
+        for j in range(3):
+            add("A", "floor", "floor", _grid_sheet((-300 + i * 100, 0, -150 + j * 100), (0, 0, 100), (100, 0, 0), 2 + (i + j) % 3, 2 + (i + j) % 3))   # (normal +y)
+    walls = [((-300, 0, -150), (600, 0, 0), (0, 250, 0), 160, 125), ((300, 0, 150), (-600, 0, 0), (0, 250, 0), 150, 110),
+             ((-300, 0, 150), (0, 0, -300), (0, 250, 0), 100, 90), ((300, 0, -150), (0, 0, 300), (0, 250, 0), 90, 80)]
+    for k, (o, du, dv, nu, nv) in enumerate(walls):   # 40,000 / 33,000 / 18,000 / 14,400 triangles
+        add("A", "wall", "bricks", _grid_sheet(o, du, dv, nu, nv, bump=1.5, rng=rng))
+    for i in range(4):
+        add("A", "ceiling", "ceiling", _grid_sheet((-300 + i * 150, 250, 150), (0, 0, -300), (150, 0, 0), 50, 40, bump=0.8, rng=rng))   # (normal -y)
+    add("A", "roof", "roof", _grid_sheet((-300, 252, -150), (600, 0, 0), (0, 0, 300), 4, 2))
+    cols = ["column_a", "column_b", "column_c"]
+    for i in range(44):
+        x, z = -280 + (i // 4) * 52.0, (-120, -45, 45, 120)[i % 4]
+        seg, rings = int(rng.choice([8, 12, 16, 24, 32])), int(rng.choice([6, 10, 16, 24]))
+        add("A", "column", cols[i % 3], _cylinder((x, 0, z), rng.uniform(5, 9), rng.uniform(120, 240), seg, rings, taper=0.15))
+    for i in range(30):
+        add("A", "detail", "details", _grid_sheet((-290 + i * 19.0, rng.uniform(20, 200), -149.0), (14, 0, 0), (0, 10, 0), 1 + i % 3, 1 + i % 2))
+    for i in range(12):   # arches between the columns: bent sheets
+        add("A", "arch", "arch", _grid_sheet((-280 + i * 48.0, 200, -120), (40, 0, 0), (0, 0, 75), 40, 20, wave=(0.5, 18.0)))
+    # B: the upper gallery (same scale, lifted) -- smaller columns, arches, details, flagpoles
+    for i in range(40):
+        x, z = -270 + (i // 2) * 28.0, (-130, 130)[i % 2]
+        add("B", "gcolumn", cols[(i + 1) % 3], _cylinder((x, 0, z), rng.uniform(3, 5), rng.uniform(50, 80), int(rng.choice([6, 8, 12])), int(rng.choice([3, 4, 8])), taper=0.1))
+    for i in range(20):
+        add("B", "garch", "arch", _grid_sheet((-270 + i * 27.0, 70, (-130, 118)[i % 2]), (24, 0, 0), (0, 0, 12), 8, 2, wave=(0.5, 6.0)))
+    for i in range(16):
+        add("B", "flagpole", "flagpole", _cylinder((-250 + i * 33.0, 10, (-100, 100)[i % 2]), 0.8, 60, 6, 2))
+    # C: props (another scale, rotated) -- vases, plants, lion heads, chains: many small meshes, a few detailed ones
+    for i in range(60):
+        mat = ["vase", "vase_round", "vase_hanging", "Material__57", "Material__25", "chain"][i % 6]
+        seg, rings = ((6, 4), (8, 6), (12, 8), (16, 12), (24, 16), (48, 32))[int(rng.choice(6, p=[0.3, 0.25, 0.2, 0.15, 0.07, 0.03]))]
+        add("C", "prop", mat, _blob((rng.uniform(-200, 200), rng.uniform(8, 60), rng.uniform(-90, 90)), rng.uniform(4, 12), seg, rings, squash=rng.uniform(0.8, 1.6)))
+    for i in range(50):
+        add("C", "chip", ["Material__47", "Material__298", "leaf"][i % 3], _grid_sheet((rng.uniform(-220, 220), rng.uniform(1, 90), rng.uniform(-100, 100)), (rng.uniform(3, 9), 0, 0), (0, rng.uniform(3, 9), 0), 1, 1 + i % 2))
+    # D: drapes (a non-uniform scale, rotated) -- wavy sheets of all seven fabric materials
+    fabrics = ["fabric_a", "fabric_c", "fabric_d", "fabric_e", "fabric_f", "fabric_g"]
+    for i in range(36):
+        nu, nv = ((10, 6), (20, 12), (40, 20), (60, 30))[int(rng.choice(4, p=[0.4, 0.3, 0.2, 0.1]))]
+        add("D", "drape", fabrics[i % 6], _grid_sheet((-260 + (i % 18) * 29.0, 60 + 70 * (i // 18), (-100, 100)[i % 2]), (26, 0, 0), (0, 60, 0), nu, nv, wave=(3.0, 2.5)))
+    # E: the far wing (rotated by a quarter turn, moved) -- more walls, columns, details
+    for i in range(3):
+        add("E", "wwall", "bricks", _grid_sheet((-150, 0, -100 + i * 100), (300, 0, 0), (0, 200, 0), 96 - 20 * i, 74 - 12 * i, bump=1.2, rng=rng))
+    for i in range(24):
+        add("E", "wcolumn", cols[i % 3], _cylinder((-140 + (i // 2) * 25.0, 0, (-60, 60)[i % 2]), rng.uniform(4, 7), rng.uniform(100, 180), int(rng.choice([8, 12, 16])), int(rng.choice([4, 8, 12])), taper=0.12))
+    for i in range(30):
+        add("E", "wdetail", ["details", "Material__298", "roof"][i % 3], _grid_sheet((-145 + i * 9.5, rng.uniform(10, 150), -99.0), (7, 0, 0), (0, 7, 0), 1, 1))
+    h2 = lambda a: (float(np.sin(a / 2)), float(np.cos(a / 2)))
+    xforms = {"A": transform(scale=(0.05, 0.05, 0.05)),                                                    # scene.rs:873-877
+              "B": transform(pos=(0.0, 6.5, 0.0), scale=(0.05, 0.05, 0.05)),
+              "C": transform(pos=(2.0, 0.0, 1.0), rot=(0, h2(0.6)[0], 0, h2(0.6)[1]), scale=(0.03, 0.03, 0.03)),
+              "D": transform(pos=(-1.0, 0.0, 0.5), rot=(0, h2(-0.4)[0], 0, h2(-0.4)[1]), scale=(0.05, 0.06, 0.05)),
+              "E": transform(pos=(0.0, 0.0, -9.0), rot=(0, h2(np.pi / 2)[0], 0, h2(np.pi / 2)[1]), scale=(0.05, 0.05, 0.05))}
+    sc = Scene()
+    sc.set_camera((0, 4, 0), (0, 4, 1))   # scene.rs:867-870
+    for key in "ABCDE":
+        _write_obj(os.path.join(work, f"hetero_{key}.obj"), "sponza_standin.mtl", G[key], with_normals=key in "AD")
+        sc.add_mesh_from_file(f"hetero_{key}.obj", xform=xforms[key], use_mtl=True, assets_dir=work)
+    hq = h2(np.pi / 2)
+    quad = np.array([[-1, -1, 0, 0, 0, 1, 0, 0], [1, -1, 0, 0, 0, 1, 1, 0], [1, 1, 0, 0, 0, 1, 1, 1], [-1, 1, 0, 0, 0, 1, 0, 1]], np.float32)
+    sc.add_mesh_from_data(quad, [0, 1, 2, 0, 2, 3], xform=transform(pos=(-15, 60, 0), rot=(hq[0], 0, 0, hq[1]), scale=(40, 20, 1)),
+                          mat=material(color=(0.7, 0.7, 0.7, 1), emission_color=(1, 1, 1, 1), specular_color=(1, 1, 1, 1),
+                                       emission_strength=4.0, smoothness=1.0))   # scene.rs:884-892
+    sc.add_sphere((5, 2, 0), 2.0, material(color=(1, 1, 1, 1), emission_color=(1, 1, 1, 1), specular_color=(1, 1, 1, 1),
+                                          emission_strength=10.0, smoothness=0.0, specular=0.0))   # scene.rs:894-908
+    sc.build()
+    return sc

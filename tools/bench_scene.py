@@ -5,6 +5,7 @@ bytes SURVEY 8(d) item (ii) asks for:
     BS_W=3840 BS_H=2160 BS_BOUNCES=8 python tools/bench_scene.py 11 64    # config 5 stand-in at full size
     python tools/bench_scene.py 0 8           # config 4 stand-in: 200 textured meshes
     BS_MESHES=340 BS_DETAIL=8 python tools/bench_scene.py 0 8    # the same at sponza.obj's size (261 k triangles)
+    BS_HETERO=1 python tools/bench_scene.py 0 8    # the heterogeneous stand-in: sponza.mtl + 25 of its textures, 393 groups, 5 transforms
 Options: BS_OPTS=name=value,... (rt_set_option, upload-time ones too), BS_FRAMES (timed frames, default: whole launches, >= 12),
 BS_BATCH (frames per launch of rt_render_frames, default 4; 1 = one launch per frame), BS_JSON=path (also write the
 figures as JSON), BS_COUNTERS=0 (skip the counter frame), BS_DEVICE_BUILD=1 (SAH searches on the GPU).
@@ -27,7 +28,10 @@ def main():
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     g = os.path.join(ROOT, "tests", "golden")
     t0 = time.perf_counter()
-    if n == 0:   # config 4 stand-in: many textured meshes
+    if n == 0 and os.environ.get("BS_HETERO"):   # config 4 stand-in with sponza.mtl's materials and textures (round 5)
+        sc = scenes.sponza_hetero()
+        name = "heterogeneous sponza stand-in (393 groups of 2 .. 40,000 triangles, 5 transforms, sponza.mtl + 25 of its textures)"
+    elif n == 0:   # config 4 stand-in: many textured meshes
         nm, detail = int(os.environ.get("BS_MESHES", 200)), int(os.environ.get("BS_DETAIL", 1))
         sc = scenes.sponza_standin(nm, detail=detail)
         name = f"sponza stand-in ({nm} textured meshes, {12 * detail * detail} triangles each)"
