@@ -2594,11 +2594,10 @@ int rt_snapshot_image(rt_handle* h, size_t bytes) {
         return fail(h, RT_ERR_INVALID_ARGUMENT, "snapshot empty or larger than the image");
     HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = wait_pending_copy(h); rc != RT_OK) return rc;
-    if (!h->copy_stream) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->snapshot_taken, hipEventDisableTiming));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->snapshot_read, hipEventDisableTiming));
-    }
+    // (each object on its own: a creation that failed half-way must not leave later calls with null events)
+    if (!h->copy_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!h->snapshot_taken) HIP_TRY(h, hipEventCreateWithFlags(&h->snapshot_taken, hipEventDisableTiming));
+    if (!h->snapshot_read) HIP_TRY(h, hipEventCreateWithFlags(&h->snapshot_read, hipEventDisableTiming));
     if (h->snapshot_capacity < bytes) {
         HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -75,7 +75,8 @@ def render(mode, w, h, frames, arrays, spp=4, bounces=5):
     tr.render_frames(rt.make_params(w, h, bounces, spp, skybox=0, frames=0), frames)
     img = tr.read_image(w, h)
     out = np.zeros((h, w, 4), np.uint8)
-    tr._check(tr._L.rt_export_rgba8(tr._h, w, h, out.ctypes.data))
+    img = np.ascontiguousarray(img, np.float32)
+    assert tr._L.rt_export_rgba8(img.ctypes.data, w, h, out.ctypes.data) == 0   # (a host function: app.rs:408-460 on the frame read back)
     return img, out
 
 
