@@ -75,6 +75,10 @@ struct rt_handle {
     // deferred walks (RenderArgs::park): the deferred mesh found at upload, the two park queues, their counters
     bool have_defer = false;
     uint32_t defer_mesh = 0, defer_xform = 0, defer_internal = 0;  // (internal nodes of its BVH)
+#if RT_WALK2
+    float4* walk2 = nullptr;           // experiment: two-level records of the deferred mesh (rt_device.h)
+    uint32_t walk2_base = 0;
+#endif
     int defer_min_nodes = 1024;  // option "defer_min_nodes": smallest BVH (internal nodes) that is worth deferring (next upload; tests lower it)
     // option "sort_rounds": walk-and-resume rounds of a deferred-walk sequence; 0 = off, -1 (default) = automatic: by
     // the work of the launch in units of one 1920 x 1080 frame at 16 samples per pixel and the size of the big mesh
@@ -559,6 +563,9 @@ void rt_destroy(rt_handle* h) {
     free_dev(h->primary);
     for (auto& st : h->slot_primary) free_dev(st.table);
     free_dev(h->pixel_cache_mem);
+#if RT_WALK2
+    free_dev(h->walk2);
+#endif
     free_dev(h->tile_cost[0]);
     free_dev(h->tile_cost[1]);
     free_dev(h->tile_order);
@@ -1018,6 +1025,24 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
             }
         }
 
+#if RT_WALK2
+        free_dev(h->walk2);
+        h->walk2 = nullptr;
+        if (have_defer) {
+            const uint32_t base = wide_base[defer_mesh];
+            std::vector<float4> w2((size_t)defer_internal * 12u, make_float4(0, 0, 0, 0));
+            auto bitsof = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+            for (uint32_t k = 0; k < defer_internal; ++k) {
+                const WideRec& w = wide[base + k];
+                for (int q = 0; q < 4; ++q) w2[(size_t)k * 12 + q] = w.q[q];
+                if (bitsof(w.q[1].w) == 0u) for (int q = 0; q < 4; ++q) w2[(size_t)k * 12 + 4 + q] = wide[bitsof(w.q[1].z)].q[q];
+                if (bitsof(w.q[3].w) == 0u) for (int q = 0; q < 4; ++q) w2[(size_t)k * 12 + 8 + q] = wide[bitsof(w.q[3].z)].q[q];
+            }
+            HIP_TRY(h, hipMalloc((void**)&h->walk2, w2.size() * sizeof(float4)));
+            HIP_TRY(h, hipMemcpy(h->walk2, w2.data(), w2.size() * sizeof(float4), hipMemcpyHostToDevice));
+            h->walk2_base = base;
+        }
+#endif
         // ---- blob layout ------------------------------------------------------
         SceneLayout lay{};
         uint64_t off = 0;
@@ -2055,6 +2080,10 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
         HIP_TRY(h, hipMemsetAsync(h->park_counts, 0, 72 * sizeof(uint32_t), h->stream));
         a.defer_mesh = h->defer_mesh;
         a.defer_xform = h->defer_xform;
+#if RT_WALK2
+        a.walk2 = h->walk2;
+        a.walk2_base = h->walk2_base;
+#endif
         auto fresh_counter = [&]() -> hipError_t {
             h->work_slot = (h->work_slot + 1) & 63u;
             if (h->work_slot == 0u) {

@@ -20,6 +20,13 @@
 #define RT_EXPERIMENTS 0
 #endif
 
+// Experiment of round 5 (tools/experiments/README.md): two-level records for rt_walk_kernel --
+// the record of an internal node carries its children's boxes AND a copy of both children's own records (192 B), so that
+// the near-first descent fetches once per two levels.  -DRT_WALK2=1 (tools/build_variant.sh walk2 -DRT_WALK2=1).
+#ifndef RT_WALK2
+#define RT_WALK2 0
+#endif
+
 namespace rtd {
 
 // The whole scene is one blob of 16-byte words, either read in place (global
@@ -235,6 +242,10 @@ struct RenderArgs {
     float4* q_out;                // where this launch parks
     uint32_t* q_out_count;
     uint32_t defer_mesh, defer_xform;  // the deferred mesh and the mesh whose matrices give its local ray
+#if RT_WALK2
+    const float4* walk2;               // 12 float4 per internal node of the deferred mesh: its wide record, then copies of
+    uint32_t walk2_base;               // its two children's wide records (zeros for a leaf child); index = wide index - base
+#endif
     // Hybrid launch of a deferred-walk sequence (option "hybrid"): `blob` / `lay` are the SMALL blob -- the scene without
     // the deferred mesh's BVH and triangles, staged into LDS -- and only a winner on the deferred mesh reads its shading
     // record from the full blob in global memory.

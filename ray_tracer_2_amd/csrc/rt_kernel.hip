@@ -2365,6 +2365,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderA
                         tri_test<40>(lo, ld, ld4<false>(a, t), ld4<false>(a, t + 16), ld4<false>(a, t + 32), cull, cur + j, b);
                     }
                 } else {
+                    DIAG(42);
                     float4 q0, q1, q2, q3;
                     load_wide<false>(a, cur, q0, q1, q2, q3);
                     const float da = aabb_dist(lo, inv, q0, q1, b.t);
@@ -2389,6 +2390,61 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderA
                 }
             }
         } else {
+#if RT_WALK2
+        // Experiment (rt_device.h RT_WALK2): one fetch serves TWO levels of the near-first descent.  The record of `cur`
+        // holds its children's boxes (the old wide record) and a copy of each child's own wide record; the second step
+        // below is the very step the next trip of the loop would make after fetching the near child's record -- the same
+        // tests against the same b.t (nothing happens in between), the same pushes in the same order.
+        while (have && cur_count == 0) {
+            DIAG(42);
+            const float4* r = a.walk2 + (size_t)(cur - a.walk2_base) * 12u;
+            const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+            const float4 ca0 = r[4], ca1 = r[5], ca2 = r[6], ca3 = r[7], cb0 = r[8], cb1 = r[9], cb2 = r[10], cb3 = r[11];
+            const float da = aabb_dist(lo, inv, q0, q1, b.t);
+            const float db = aabb_dist(lo, inv, q2, q3, b.t);
+            if (STATS) node_tests += 2;
+            const bool left_closer = da < db;
+            const float near_d = left_closer ? da : db, far_d = left_closer ? db : da;
+            const uint32_t near_i = fbits(left_closer ? q1.z : q3.z), near_c = fbits(left_closer ? q1.w : q3.w);
+            const uint32_t far_i = fbits(left_closer ? q3.z : q1.z), far_c = fbits(left_closer ? q3.w : q1.w);
+            if (far_d < b.t) {
+                stack_put(st, sp, far_i, far_c);
+                ++sp;
+            }
+            if (near_d < b.t) {
+                cur = near_i;
+                cur_count = near_c;
+                if (cur_count == 0) {   // the near child is internal: its step, from the copy of its record
+                    const float4 n0 = left_closer ? ca0 : cb0, n1 = left_closer ? ca1 : cb1, n2 = left_closer ? ca2 : cb2, n3 = left_closer ? ca3 : cb3;
+                    const float ea = aabb_dist(lo, inv, n0, n1, b.t);
+                    const float eb = aabb_dist(lo, inv, n2, n3, b.t);
+                    if (STATS) node_tests += 2;
+                    const bool l2 = ea < eb;
+                    const float near2 = l2 ? ea : eb, far2 = l2 ? eb : ea;
+                    const uint32_t near2_i = fbits(l2 ? n1.z : n3.z), near2_c = fbits(l2 ? n1.w : n3.w);
+                    const uint32_t far2_i = fbits(l2 ? n3.z : n1.z), far2_c = fbits(l2 ? n3.w : n1.w);
+                    if (far2 < b.t) {
+                        stack_put(st, sp, far2_i, far2_c);
+                        ++sp;
+                    }
+                    if (near2 < b.t) {
+                        cur = near2_i;
+                        cur_count = near2_c;
+                    } else if (sp == 0) {
+                        have = false;
+                    } else {
+                        --sp;
+                        stack_get(st, sp, cur, cur_count);
+                    }
+                }
+            } else if (sp == 0) {
+                have = false;
+            } else {
+                --sp;
+                stack_get(st, sp, cur, cur_count);
+            }
+        }
+#else
         while (have && cur_count == 0) {  // descend to the next leaf (traverse_mesh's step)
             DIAG(42);
             float4 q0, q1, q2, q3;
@@ -2414,6 +2470,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 8) rt_walk_kernel(const RenderA
                 stack_get(st, sp, cur, cur_count);
             }
         }
+#endif
         if (have) {  // a leaf
             if (STATS) tri_tests += (int)cur_count;
             for (uint32_t j = 0; j < cur_count; ++j) {
