@@ -355,9 +355,9 @@ int rt_bind_image(rt_handle* h, void* device_ptr, uint64_t texels);
  *                                                 LDS-resident scene and a share too small for a launch of its own to keep the lanes
  *                                                 full (batches of about 4 ms: 28 / 14 / 7 frames for a strip share of 8 / 4 / 2 ranks
  *                                                 of config 2, none for the whole frame), reached by doubling from 2 so that a
- *                                                 sequence of n frames renders at most n in vain; for a scene read from global memory
- *                                                 (many meshes, a big mesh) up to 8 frames and about 33 ms by a work estimate, nothing
- *                                                 for frames of 8 ms and more; 0 = off; 2 .. 64 = that many frames per batch whatever
+ *                                                 sequence of n frames renders at most n in vain; never for a scene read from global
+ *                                                 memory (rays of unknown cost: a host asks for batches there itself -- frame_ahead = 8:
+ *                                                 config 5's geometry 4.43 -> 3.40 ms per call); 0 = off; 2 .. 64 = that many frames per batch whatever
  *                                                 the host does (the first call of a batch returns its frame after the whole batch).
  *                                                 rt_get_stats: `frames` counts the frames asked for, `frames_speculative` the ones
  *                                                 rendered ahead that no call has asked for (yet); rays and times include both

@@ -121,11 +121,6 @@ struct rt_handle {
     // such a host opts in with an explicit depth (frame_ahead = 2 .. 64).
     int frame_ahead = -1;                              // -1 automatic (ahead_depth()), 0 off, 2 .. RT_MAX_BATCH_FRAMES frames
     bool frame_ahead_failed = false;                   // the batch could not be set up once (memory): automatic stays off
-    // The automatic rule for scenes read from global memory rests on a work ESTIMATE; the first batch is timed (its launch's
-    // events, read once they have completed) and a scene whose frames turn out slower than the rule assumes -- more than
-    // 33 ms / 4 each -- keeps a launch per call from then on (until the next scene upload).
-    struct { hipEvent_t first = nullptr, second = nullptr; uint32_t n = 0; bool pending = false; } ahead_probe;
-    bool ahead_slow = false;
     uint32_t ahead_ramp = 2;                           // automatic: batches of 2, 4, 8, ... frames up to ahead_depth() while the
                                                        // sequence goes on, so that a host that stops after n frames has had
                                                        // at most n rendered in vain; back to 2 when the sequence breaks
@@ -1246,8 +1241,6 @@ int rt_upload_scene(rt_handle* h, const rt_scene_uniform* scene, const rt_sphere
         h->history_valid = false;
         h->primary_valid = false;  // (the table holds hits: a function of the scene)
         for (auto& st : h->slot_primary) st.valid = false;
-        h->ahead_slow = false;
-        h->ahead_probe.pending = false;
     } catch (const std::bad_alloc&) {
         return fail(h, RT_ERR_OUT_OF_MEMORY, "out of host memory");
     }
@@ -1384,7 +1377,6 @@ int rt_set_option(rt_handle* h, const char* name, int value) {
             return fail(h, RT_ERR_INVALID_ARGUMENT, "frame_ahead must be -1 (automatic), 0 (off) or 2 .. 64 (frames per batch)");
         h->frame_ahead = value;
         h->frame_ahead_failed = false;
-        h->ahead_slow = false;
     } else if (n == "fast_miss") {
         h->fast_miss = value ? 1 : 0;
     } else if (n == "park_levels") {
@@ -1978,7 +1970,6 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             // the pool is full: add the recorded times to the running total, then reuse the events
             HIP_TRY(h, harvest_event_times(h, h->ev_ms_harvested));
             h->ev_used = 0;
-            h->ahead_probe.pending = false;  // (the events are about to be recorded again)
         } else {
             hipEvent_t s0 = nullptr, s1 = nullptr;
             HIP_TRY(h, hipEventCreate(&s0));
@@ -2247,18 +2238,10 @@ static uint32_t ahead_depth(const rt_handle* h, const rt_params* params, uint64_
     if (h->frame_ahead_failed || host_waits) return 0;
     const double segments = (double)need_texels * (double)params->rays_per_pixel *
                             (double)((params->number_of_bounces < 0 ? 0 : params->number_of_bounces) + 1);
-    if (!h->lds_scene || h->force_global) {
-        if (h->ahead_slow) return 0;
-        // Scenes read from global memory (many meshes, a big mesh): their rays cost about five times an LDS-resident
-        // scene's, a launch per frame leaves more undone (the deferred walks of a big mesh need batches at all), and what a
-        // batch returns is larger -- config 5's geometry 4.43 -> 3.40 ms per call at 8 frames, the 200-mesh stand-in 3.50 ->
-        // 3.16, the sponza-sized one 5.95 -> 5.65 -- so the bound is looser: about two display refreshes (33 ms) by this
-        // estimate, at most 8 frames, and nothing for frames that fill such a batch by themselves.
-        const double ms_est = segments / (1920.0 * 1080.0 * 8.0 * 5.0) * 1.13 * 5.0;
-        const double dn = 33.0 / (ms_est > 1e-3 ? ms_est : 1e-3);
-        const uint32_t nn = dn >= 8.0 ? 8u : (uint32_t)dn;
-        return nn >= 4u ? nn : 0u;
-    }
+    // (Scenes read from global memory: rays of unknown cost -- the rule of round 4, "up to 8 frames and about 33 ms by a
+    // work estimate", guessed a frame time and needed a timing probe to take the guess back; a host that wants batches on
+    // such a scene asks for them: frame_ahead = 8 gives config 5's geometry 4.43 -> 3.40 ms per call.)
+    if (!h->lds_scene || h->force_global) return 0;
     const double ms = segments / (1920.0 * 1080.0 * 8.0 * 5.0) * 1.13;
     const double d = 4.0 / (ms > 1e-3 ? ms : 1e-3);
     const uint32_t n = d >= (double)RT_MAX_BATCH_FRAMES ? RT_MAX_BATCH_FRAMES : (uint32_t)d;
@@ -2328,14 +2311,6 @@ static int render_single(rt_handle* h, const rt_params* params, uint32_t rank, u
         // (a host that WAITS for its frames finds the stream idle; one that runs ahead of the device finds it busy)
         const bool host_waits = h->frame_ahead < 0 && !(hipSetDevice(h->device) == hipSuccess && hipStreamQuery(h->stream) == hipErrorNotReady);
         (void)hipGetLastError();  // (hipErrorNotReady is an answer, not a failure: not for the launchers' hipGetLastError)
-        if (h->ahead_probe.pending && hipEventQuery(h->ahead_probe.second) == hipSuccess) {
-            float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, h->ahead_probe.first, h->ahead_probe.second) == hipSuccess && h->ahead_probe.n > 0u &&
-                !(h->lds_scene && !h->force_global) && ms / (float)h->ahead_probe.n > 33.0f / 4.0f)
-                h->ahead_slow = true;
-            h->ahead_probe.pending = false;
-        }
-        (void)hipGetLastError();
         uint32_t d = ahead_depth(h, params, need_texels, host_waits);
         if (h->frame_ahead < 0 && d >= 2) {
             // (room for the full depth at once: the batches on the way up would each re-allocate the scratch images -- a
@@ -2358,12 +2333,6 @@ static int render_single(rt_handle* h, const rt_params* params, uint32_t rank, u
         if (d >= 2 && need_texels <= h->image_texels) {
             int rc = render_impl(h, params, rank, world, d, true);
             if (rc == RT_OK) {
-                if (h->frame_ahead < 0 && h->ev_used > 0 && !h->ahead_probe.pending) {   // (time this batch: see ahead_probe)
-                    h->ahead_probe.first = h->ev_pool[h->ev_used - 1].first;
-                    h->ahead_probe.second = h->ev_pool[h->ev_used - 1].second;
-                    h->ahead_probe.n = d;
-                    h->ahead_probe.pending = true;
-                }
                 h->ahead.valid = true;
                 h->ahead.base = *params;
                 h->ahead.n = d;
@@ -2714,7 +2683,6 @@ int rt_reset_timing(rt_handle* h) {
     // memset: the zeroing is complete before the call returns, so no later launch's counter adds can race with it)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->ev_used = 0;
-    h->ahead_probe.pending = false;
     h->ev_ms_harvested = 0.0;
     h->launches_total = h->frames_total = h->frames_speculative = 0;
     h->paths_total = 0;
@@ -2729,7 +2697,6 @@ int rt_set_stream(rt_handle* h, void* hip_stream) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, harvest_event_times(h, h->ev_ms_harvested));  // (the old stream is idle: its recorded times are final)
     h->ev_used = 0;
-    h->ahead_probe.pending = false;
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return RT_OK;
 }
