@@ -266,7 +266,7 @@ struct rt_handle {
     // round 5: its exactness rests on "a triangle hit at t is not found under a box entered far beyond t", which holds for
     // every random ray ever compared (102 G) but NOT for a ray that grazes a far triangle at ~1e-6 rad from an origin within
     // ~1e-4 of that triangle's plane in a generic orientation -- there the shader's own t = dot(ao, n) / det is a quotient of
-    // two cancelling sums (tools/prune_directed.py: leaf-box entry up to 1.45 t; tests/test_gpu_prune_directed.py: 1 texel of
+    // two cancelling sums (tools/prune_directed.py: leaf-box entry up to 1.55 t; tests/test_gpu_prune_directed.py: 1 texel of
     // 2 M directed rays differs).  A host that prefers 45 % less time on many-mesh scenes over that switches it on.
     int cross_prune = 0;
     int force_global = 0;  // option "lds_scene" = 0 disables LDS staging (tuning / tests)

@@ -9,7 +9,7 @@ so that the far geometry's boxes are what a pruned walk refuses.  8 families x 1
 What is asserted: the DEFAULT kernels (cross_prune = 0 since round 5) equal the oracle bit for bit on every family, from LDS
 and from global memory.  What is reported (gpurun_out/prune_directed.txt, cited in DESIGN.md): the texels in which the
 opt-in pruned kernels (cross_prune = 1) differ.  In the families in a generic orientation the shader's own
-t = dot(ao, n) / det is a quotient of two cancelling sums and the oracle's census finds leaf-box entry distances up to 1.45 x
+t = dot(ao, n) / det is a quotient of two cancelling sums and the oracle's census finds leaf-box entry distances up to 1.55 x
 the reported t (tools/prune_directed.py, profiles/r05_prune_directed_census.txt): that is the geometry the pruning's 12.5 %
 slack does not cover, and why it is no longer the default."""
 import os

@@ -83,6 +83,24 @@ for seed in range(first, first + count):
     if not np.array_equal(tr.read_image(w, h).view(np.uint32), acc.view(np.uint32)):
         bad += 1
         print(f"MISMATCH seed {seed} rt_render_frames")
+    # (round 5) the scene read from global memory, whatever its size: the primary-ray memo read in place from the primary table
+    # (memo_in_table = 1, the default) and copied into the per-wave buffer (0); one batch and three single-frame calls each
+    tr.set_option("lds_scene", 0)
+    for mit in (1, 0):
+        tr.set_option("memo_in_table", mit)
+        tr.write_image(np.zeros((h, w, 4), np.float32))
+        tr.render_frames(p, 3)
+        ok = np.array_equal(tr.read_image(w, h).view(np.uint32), acc.view(np.uint32))
+        tr.write_image(np.zeros((h, w, 4), np.float32))
+        for f in range(3):
+            p.frames = f
+            tr.render(p)
+        p.frames = 0
+        if not (ok and np.array_equal(tr.read_image(w, h).view(np.uint32), acc.view(np.uint32))):
+            bad += 1
+            print(f"MISMATCH seed {seed} global memory, memo_in_table = {mit}")
+    tr.set_option("memo_in_table", 1)
+    tr.set_option("lds_scene", 1)
     # deferred walks: the biggest BVH mesh of the scene, however small, walked by rt_walk_kernel (few-mesh scenes)
     if not (MANY or seed % 4 == 3):
         tr.set_option("defer_min_nodes", 1)

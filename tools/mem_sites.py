@@ -70,7 +70,10 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     g = os.path.join(ROOT, "tests", "golden")
-    if n == 0:
+    if n == 0 and os.environ.get("BS_HETERO"):
+        sc = scenes.sponza_hetero()
+        name = "heterogeneous sponza stand-in (393 groups, 259 k triangles, 5 transforms)"
+    elif n == 0:
         nm, detail = int(os.environ.get("BS_MESHES", 340)), int(os.environ.get("BS_DETAIL", 8))
         sc = scenes.sponza_standin(nm, detail=detail)
         name = f"sponza stand-in ({nm} meshes x {12 * detail * detail} triangles)"
