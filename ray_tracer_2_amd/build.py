@@ -20,7 +20,7 @@ PRODUCT_SOURCES = [
 PRODUCT_HEADERS = [
     "rt_transc.h", "rt_texture.h", "rt_srgb_lut.h", "rt_device.h", "rt_rccl.h", "host/glam_math.h",
     "host/obj_loader.h", "host/bvh.h", "host/scene.h", "host/ray_tracer.hpp",
-    "../../include/rt_abi.h", "../../include/rt_test_abi.h", "experiments/rt_wavefront.inl", "experiments/rt_wavefront_launch.inl",
+    "../../include/rt_abi.h", "../../include/rt_test_abi.h", "experiments/rt_wavefront.inl", "experiments/rt_wavefront_launch.inl", "experiments/rt_api_wavefront.inl", "experiments/rt_api_hybrid_blob.inl",
 ]
 
 
