@@ -137,6 +137,8 @@ def material_from_mtl(m):
     spec = m.get("Ks", [f32(1.0)] * 3)
     illum = m.get("illum", 0)
     flag = 1 if illum in (4, 6, 9) else 0
+    if "map_Kd" in m or "map_Disp" in m["unknown"]:   # asset.rs:151-162: a diffuse or a "map_Disp" texture makes it TEXTURE
+        flag = 2
     es = f32(0.0)
     ecol = [f32(0)] * 3
     if "Ke" in m["unknown"]:
