@@ -102,3 +102,32 @@ def test_a_pipeline_deeper_than_the_hardware_queues_is_said_once(rt, cornell):
         t.synchronize()
     finally:
         t.close()
+
+
+def test_max_device_mb_switches_the_deferred_walks_off_not_the_image(rt):
+    """A big-mesh scene whose batches defer the mesh's walks (two park queues: 2 x 144 B per pixel and frame): under a cap that
+    leaves no room for the queues the same frames come from the plain kernels -- another frame time, the same bits."""
+    import os
+    from conftest import ROOT
+    from ray_tracer_2_amd import scenes
+    g = os.path.join(ROOT, "tests", "golden")
+    a = rt.SceneArrays.from_scene(scenes.cornell_dragon(scenes.load_raw_meshes(os.path.join(g, "cornell_raw.npz")),
+                                                        scenes.load_raw_meshes(os.path.join(g, "dragon_raw.npz")), subdivide=3))
+    w, h, nf = 1920, 1080, 8   # (8 units of work: the automatic rule defers from there; the queues would take 7.4 GB)
+    imgs, deferred = [], []
+    for cap in (0, 300):
+        t = rt.RayTracer(device=0, max_width=w, max_height=h)
+        try:
+            t.set_option("max_device_mb", cap)
+            t.set_option("batch_frames", nf)
+            t.load_scene(a)
+            t.render_frames(rt.make_params(w, h, 4, 16, skybox=1, frames=0), nf)
+            imgs.append(t.read_image(w, h).copy())
+            ll = t.last_launch()
+            deferred.append(ll["deferred_walks"])
+            if cap:
+                assert ll["device_mb_held"] <= cap, ll
+        finally:
+            t.close()
+    assert deferred == [True, False], deferred
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
