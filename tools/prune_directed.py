@@ -109,7 +109,7 @@ def _rotate(sc_meshes, R):
     return out
 
 
-def blades(slivers=False, rot=None, pencil=4e-4, segments=4, betas=None, n_blades=24):
+def blades(slivers=False, rot=None, pencil=4e-4, segments=4, betas=None, n_blades=24, n_occluders=8):
     """rot: a 3 x 3 rotation applied to the whole configuration, camera included.  Axis-aligned (rot = None) the sums
     dot(ao, n) and dot(dir, n) of wgsl:266,273 have one dominant term each and hardly cancel; in a generic orientation every
     term is of the size of |ao| |n| and the sums are what is left of them: the case to aim at."""
@@ -138,9 +138,9 @@ def blades(slivers=False, rot=None, pencil=4e-4, segments=4, betas=None, n_blade
             k += 1
     # near occluders: stripes across the view at depths up to just inside 60 / 1.125
     depths = [30.0, 40.0, 45.0, 50.0, 52.0, 53.0, 53.3, 48.0]
-    for j, z in enumerate(depths):
-        x0 = (-0.5 + j * 0.125) * pencil * z
-        x1 = x0 + 0.075 * pencil * z
+    for j, z in enumerate(depths[:n_occluders]):
+        x0 = (-0.5 + j * 0.125 * 8 / n_occluders) * pencil * z
+        x1 = x0 + 0.075 * 8 / n_occluders * pencil * z
         v, idx = _strip((x0, -0.5 * pencil * z, z), (x1, -0.5 * pencil * z, z), (x0, 0.5 * pencil * z, z), (x1, 0.5 * pencil * z, z), 2, flip=True)
         meshes.append((v, idx, _mat(k)))
         k += 1
@@ -245,7 +245,11 @@ def families():
             ("blades_rotated", blades(rot=R, pencil=4e-5, segments=32, betas=wide, n_blades=12)),
             ("blades_rotated_narrow", blades(rot=R, pencil=4e-6, segments=32, betas=[b * 0.1 for b in wide], n_blades=12)),
             ("blades_slivers_rotated", blades(slivers=True, rot=R, pencil=4e-5, betas=wide)),
-            ("faces", faces()), ("large", large()), ("ties", ties())]
+            ("faces", faces()), ("large", large()), ("ties", ties()),
+            # the same grazing geometry on the FEW-mesh kernels (forest and two-leaf items, the headline's kernel family): 2 strips
+            # (4 meshes) and 2 occluders, axis-aligned and in the generic orientation
+            ("few_blades", blades(n_blades=2, n_occluders=2)),
+            ("few_blades_rotated", blades(rot=R, pencil=4e-5, segments=32, betas=wide, n_blades=2, n_occluders=2))]
 
 
 def main():
