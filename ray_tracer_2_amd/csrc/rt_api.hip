@@ -20,13 +20,13 @@
 #include <vector>
 
 #include "rt_device.h"
-#include "rt_rccl.h"
+#include "rt_rccl.h"  // (types of <rccl/rccl.h>; the library itself is loaded on first multi-device use)
 #ifndef RT_TEST_ENTRIES
 #define RT_TEST_ENTRIES 0
 #endif
 #if RT_TEST_ENTRIES
 #include "../../include/rt_test_abi.h"
-#endif  // (types of <rccl/rccl.h>; the library itself is loaded on first multi-device use)
+#endif
 #include "rt_srgb_lut.h"
 
 namespace rtd {
