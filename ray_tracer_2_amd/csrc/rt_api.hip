@@ -1978,8 +1978,11 @@ static int render_impl(rt_handle* h, const rt_params* params, uint32_t rank, uin
             ah.stack_wide = 0;
             ah.pixel_cache = h->pixel_cache_opt ? 1u : 0u;
             if (ah.pixel_cache && render_lds_bytes(ah) > LDS_BUDGET_BYTES) {
-                ah.pixel_cache = a.pixel_cache == 2u ? 2u : 0u;   // (the global-memory memo the plain launches use, if they have one)
-                ah.pixel_cache_mem = a.pixel_cache_mem;
+                // (the global-memory memo buffer; the plain launches may read theirs in place from the table -- pixel_cache 4 --,
+                // which the LDS-scene kernels of the hybrid launches have not compiled in: a parked pixel's memo is rebuilt from
+                // the table on resume either way, RenderArgs::primary_complete)
+                ah.pixel_cache = (a.pixel_cache == 2u || a.pixel_cache == 4u) && h->pixel_cache_mem ? 2u : 0u;
+                ah.pixel_cache_mem = h->pixel_cache_mem;
             }
             if (!ah.pixel_cache) ah.primary = nullptr;
             ah.fast_miss = h->fast_miss != 0 && ah.pixel_cache != 0u ? 1u : 0u;
